@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Throughput of the Huffman hot path on MI355X.
+
+One step = one full pass of the path over a synthetic byte stream that is
+already resident in HBM:  histogram -> host codebook -> device tables ->
+encode (+ gap array) -> decode.  `value` is uncompressed GB/s of that round
+trip (bytes of all ranks / max-over-ranks time); encode-only and decode-only
+rates and per-kernel durations (HIP events on the launch stream, inside the
+timed region) are reported alongside.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+N=1: 1 GiB Zipf(s=1.1) stream.  N>1 (launched by torch.distributed.run, one
+rank per GPU): every rank owns a contiguous 2 GiB shard of one logical stream
+(N=8 -> the 16 GiB configuration); the 256-bin histograms are all-reduced over
+RCCL, every rank builds the same codebook, the shards' bit lengths are
+all-gathered and scanned so that each shard is encoded at its own bit phase of
+the global stream.  The compressed shards stay where they are unless --gather.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from huffman_amd import device as hd  # noqa: E402
+from huffman_amd import synth  # noqa: E402
+from huffman_amd.dist import ShardPlan, plan_shards  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform", "geometric", "testfile"])
+    ap.add_argument("--gib", type=float, default=None, help="GiB per GPU (default 1, or 2 when N>1)")
+    ap.add_argument("--chunk-syms", type=int, default=hd.DEFAULT_CHUNK_SYMS)
+    ap.add_argument("--enc-mode", type=int, default=1)
+    ap.add_argument("--gather", action="store_true", help="also gather the shards to rank 0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=2024)
+    return ap.parse_args()
+
+
+class Stage:
+    """Accumulates HIP-event durations of one kernel group."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def start(self):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.pairs.append((e0, e1))
+
+    def stop(self):
+        self.pairs[-1][1].record()
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(1, len(self.pairs))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    gib = args.gib if args.gib is not None else (1.0 if world == 1 else 2.0)
+    n = int(gib * (1 << 30))
+    data = synth.generate_device(args.kind, n, seed=args.seed + rank, device=dev)
+    ctx = hd.Context.get(dev)
+    ctx.set_option("enc_mode", args.enc_mode)
+    cs = args.chunk_syms
+
+    d_hist = torch.empty(256, dtype=torch.int64, device=dev)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    dres = torch.zeros(4, dtype=torch.int64, device=dev)
+    st_hist, st_enc, st_dec = Stage(), Stage(), Stage()
+    bufs = None
+    state = {}
+
+    def step(timed: bool):
+        nonlocal bufs
+        # pass 1: histogram (+ all-reduce of 2 KiB over RCCL)
+        if timed:
+            st_hist.start()
+        hd.histogram_async(data, d_hist)
+        if timed:
+            st_hist.stop()
+        local_hist = d_hist.clone() if world > 1 else d_hist
+        if world > 1:
+            dist.all_reduce(d_hist, op=dist.ReduceOp.SUM)
+        hist = d_hist.cpu().numpy().astype(np.uint64)
+        # host: codebook, then device tables
+        codes, lens = hd.build_codebook(hist)
+        model = hd.DeviceModel(codes, lens, device=dev)
+        # cross-GPU exclusive scan of the shards' bit lengths
+        lead = 0
+        plan = None
+        if world > 1:
+            my_bits = int((local_hist.cpu().numpy().astype(np.uint64) * lens).sum())
+            plan = plan_shards(my_bits, dist, dev)
+            lead = plan.lead_bits
+        if bufs is None:
+            cap = hd.DeviceModel.encode_bound(model, n, 7)
+            bufs = hd.EncodeBuffers(model, n, cs, out_cap=cap)
+        # pass 2: encode
+        if timed:
+            st_enc.start()
+        hd.encode_async(data, model, bufs, lead_bits=lead)
+        if timed:
+            st_enc.stop()
+        # the stream length is needed on the host (and is known from the histogram)
+        total_bits = int((hist * lens).sum()) if world == 1 else my_bits
+        nbytes = (lead + total_bits + 7) // 8
+        if args.gather and world > 1:
+            plan.gather(bufs.data[:nbytes], dist)
+        # decode from the gap array
+        if timed:
+            st_dec.start()
+        hd.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
+        if timed:
+            st_dec.stop()
+        state.update(model=model, nbytes=nbytes, total_bits=total_bits, lens=lens, hist=hist)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was timed: flags clear, round trip exact
+    flags = int(bufs.result[1].item()) | int(dres[1].item())
+    ok = flags == 0 and int(bufs.result[0].item()) == state["total_bits"] and torch.equal(out, data)
+    if world > 1:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
+
+    ms_step = elapsed / args.steps * 1e3
+    total_bytes = n * world
+    value = total_bytes / (elapsed / args.steps) / 1e9
+    C = state["nbytes"]
+    hist_ms, enc_ms, dec_ms = st_hist.mean_ms(), st_enc.mean_ms(), st_dec.mean_ms()
+    kernels = {
+        "histogram": {"ms": hist_ms, "alg_bytes": n},
+        "encode": {"ms": enc_ms, "alg_bytes": n + C},
+        "decode": {"ms": dec_ms, "alg_bytes": C + n},
+    }
+    for k in kernels.values():
+        k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+    dom = max(("encode", "decode"), key=lambda k: kernels[k]["ms"])
+    roofline = {
+        "bound": "hbm",
+        "kernel": {"encode": "enc_pack_kernel", "decode": "dec_kernel"}[dom],
+        "achieved": round(kernels[dom]["GBps"], 1),
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBPS, 4),
+        "traffic": None,
+    }
+
+    result = {
+        "metric": "encode+decode GB/s (uncompressed)",
+        "value": round(value, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": f"synthetic {args.kind} bytes, seed {args.seed}+rank, generated in HBM",
+        "config": {
+            "workload": (f"{gib:g} GiB {args.kind} stream per GPU x {world} GPU: histogram + host "
+                         "codebook + encode + gap-array decode"),
+            "bytes_per_gpu": n,
+            "chunk_syms": cs,
+            "enc_mode": args.enc_mode,
+            "compressed_ratio": round(C / n, 4),
+            "max_code_len": int(state["lens"].max()),
+            "gather_to_root": bool(args.gather),
+        },
+        "roundtrip_ok": ok,
+        "encode_GBps_uncompressed": round(n / (enc_ms * 1e-3) / 1e9, 1),
+        "decode_GBps_uncompressed": round(n / (dec_ms * 1e-3) / 1e9, 1),
+        "histogram_GBps": round(kernels["histogram"]["GBps"], 1),
+        "kernel_ms": {k: round(v["ms"], 4) for k, v in kernels.items()},
+        "hbm_frac": {k: round(v["GBps"] / HBM_PEAK_GBPS, 4) for k, v in kernels.items()},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(data, args.cpu_sample_mib)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("round trip mismatch")
+
+
+def cpu_baseline(data: torch.Tensor, sample_mib: int) -> dict:
+    """The CPU restatement of the reference (oracle/oracle.c), single thread, on
+    the leading sample of the same stream: from_slice + write + flush + read."""
+    import oracle
+
+    oracle.build()
+    m = min(data.numel(), sample_mib << 20)
+    host = data[:m].cpu().numpy()
+    t0 = time.perf_counter()
+    hist = oracle.histogram(host)
+    codes, lens = oracle.generate_extended_codewords(hist)
+    t1 = time.perf_counter()
+    stream, _ = oracle.encode_slice(host, codes, lens)
+    t2 = time.perf_counter()
+    back = oracle.decode_read(stream, codes, lens, m)
+    t3 = time.perf_counter()
+    assert np.array_equal(back, host)
+    return {
+        "value": round(m / (t3 - t0) / 1e9, 4),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {m >> 20} MiB of the same stream; histogram+codebook {t1 - t0:.2f}s, "
+                  f"encode {t2 - t1:.2f}s, decode {t3 - t2:.2f}s",
+        "encode_GBps": round(m / (t2 - t0) / 1e9, 4),
+        "decode_GBps": round(m / (t3 - t2) / 1e9, 4),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,319 @@
+// Host-side codebook construction and decode-table layout.
+//
+// The codebook is a <=256-element problem that the reference solves on the
+// host in microseconds (src/huffman/mod.rs:71-206); it stays on the host here
+// and only its result is staged into device memory.  The functions below give
+// the same results as the reference's but are organised differently: code
+// lengths come from an explicit two-queue Huffman merge followed by a
+// leaf-depth census instead of the in-place three-phase array rewrite.
+#include "hfgpu.h"
+#include "hfgpu_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace hf {
+
+// Lengths for weights sorted in non-increasing order.
+// Equivalent to calculate_codeword_length_inplace (src/huffman/mod.rs:71-125):
+//  * the two smallest available nodes are merged repeatedly; when a leaf and an
+//    internal node weigh the same the leaf is taken first (the reference's
+//    internal-node test is a strict `<`, mod.rs:77,85);
+//  * only the NUMBER of leaves on each depth is kept; depths are then handed
+//    out from the heaviest weight down (mod.rs:105-124), so the result is
+//    non-decreasing even among equal weights.
+int code_lengths_sorted(uint64_t *w, uint64_t n)
+{
+    if (n == 0)
+        return HF_ERR_EMPTY;
+    if (n == 1) {
+        w[0] = 0;
+        return HF_OK;
+    }
+    // Internal nodes are created in non-decreasing weight order, so a FIFO of
+    // them plus a cursor over the leaves (lightest = last) is a priority queue.
+    std::vector<uint64_t> iw(n - 1);       // weight of internal node k
+    std::vector<uint32_t> parent(n - 1);   // parent of internal node k
+    uint64_t made = 0, used = 0;           // internal nodes created / consumed
+    int64_t leaf = (int64_t)n - 1;         // next unused leaf (lightest first)
+    auto take = [&](uint32_t owner) -> uint64_t {
+        bool use_internal = leaf < 0 || (used < made && iw[used] < w[leaf]);
+        if (use_internal) {
+            parent[used] = owner;
+            return iw[used++];
+        }
+        return w[leaf--];
+    };
+    for (uint64_t k = 0; k + 1 < n; ++k) {
+        uint64_t a = take((uint32_t)k);
+        uint64_t b = take((uint32_t)k);
+        iw[k] = a + b;
+        made = k + 1;
+    }
+    // Depth of every internal node; the root is the last one created.
+    std::vector<uint32_t> depth(n - 1);
+    depth[n - 2] = 0;
+    for (int64_t k = (int64_t)n - 3; k >= 0; --k)
+        depth[k] = depth[parent[k]] + 1;
+    // Census: a full binary tree level d holds 2 * (internal nodes on level
+    // d-1) nodes; those that are not internal are leaves.
+    std::vector<uint64_t> internal_on(n + 1, 0);
+    for (uint64_t k = 0; k + 1 < n; ++k)
+        internal_on[depth[k]] += 1;
+    uint64_t next = 0, avail = 1;
+    for (uint64_t d = 0; next < n; ++d) {
+        uint64_t leaves = avail - internal_on[d];
+        for (uint64_t i = 0; i < leaves && next < n; ++i)
+            w[next++] = d;
+        avail = 2 * internal_on[d];
+        if (avail == 0)
+            break;
+    }
+    return HF_OK;
+}
+
+// (index, count) of the non-zero entries, heaviest first.  The reference uses
+// an unstable sort (src/huffman/mod.rs:138) whose order among equal counts is
+// unspecified; the rule here is: equal counts stay in ascending index order.
+int sort_nonzero_desc(const uint64_t *store, uint64_t n, uint64_t *idx, uint64_t *cnt, uint64_t *m)
+{
+    if (n > 256)
+        return HF_ERR_BAD_ARG; // assert at mod.rs:128
+    uint32_t order[256];
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        if (store[i] > 0)
+            order[k++] = (uint32_t)i;
+    std::stable_sort(order, order + k,
+                     [&](uint32_t a, uint32_t b) { return store[a] > store[b]; });
+    for (uint64_t i = 0; i < k; ++i) {
+        idx[i] = order[i];
+        cnt[i] = store[order[i]];
+    }
+    *m = k;
+    return HF_OK;
+}
+
+// Canonical codes for non-decreasing lengths
+// (src/huffman/mod.rs:155-171): the left-aligned ("big") code advances by one
+// unit of the previous length; the right-aligned code is its top len bits.
+int canonical_codes(const uint64_t *len, uint64_t n, uint64_t *small_codes, uint64_t *big_codes)
+{
+    if (n == 0)
+        return HF_ERR_EMPTY;
+    const uint64_t maxlen = len[n - 1];
+    if (maxlen > 63)
+        return HF_ERR_BAD_CODEBOOK;
+    uint64_t left = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (len[i] > maxlen)
+            return HF_ERR_BAD_CODEBOOK;
+        if (i > 0)
+            left += (uint64_t)1 << (maxlen - len[i - 1]);
+        big_codes[i] = left;
+        small_codes[i] = i == 0 ? 0 : left >> (maxlen - len[i]);
+    }
+    return HF_OK;
+}
+
+int build_codebook(const uint64_t *hist, uint64_t n, uint64_t codes[256], uint64_t lens[256])
+{
+    uint64_t idx[256], w[256], small_codes[256], big_codes[256], m = 0;
+    int rc = sort_nonzero_desc(hist, n, idx, w, &m);
+    if (rc != HF_OK)
+        return rc;
+    if (m == 0)
+        return HF_ERR_EMPTY;
+    rc = code_lengths_sorted(w, m);
+    if (rc != HF_OK)
+        return rc;
+    if (m == 1)
+        w[0] = 1; // a lone symbol still costs one bit (mod.rs:187-189)
+    rc = canonical_codes(w, m, small_codes, big_codes);
+    if (rc != HF_OK)
+        return rc;
+    std::memset(codes, 0, 256 * sizeof(uint64_t));
+    std::memset(lens, 0, 256 * sizeof(uint64_t));
+    for (uint64_t i = 0; i < m; ++i) {
+        codes[idx[i]] = small_codes[i];
+        lens[idx[i]] = w[i];
+    }
+    return HF_OK;
+}
+
+uint64_t sentinel_of(const uint64_t lens[256])
+{
+    uint64_t s = 0;
+    for (int i = 0; i < 256; ++i)
+        s = std::max(s, lens[i]);
+    return s;
+}
+
+// Model::to_btreemap (src/huffman/mod.rs:27-38) as sorted parallel arrays.
+// A later symbol replaces an earlier one with the same key, as
+// BTreeMap::insert does.
+int model_table(const uint64_t codes[256], const uint64_t lens[256], uint64_t keys[256],
+                uint8_t syms[256], uint8_t klens[256], uint64_t *m)
+{
+    const uint64_t s = sentinel_of(lens);
+    if (s > 64)
+        return HF_ERR_CODELEN;
+    struct Ent {
+        uint64_t key;
+        uint8_t sym, len;
+    };
+    std::vector<Ent> ents;
+    for (int ix = 0; ix < 256; ++ix) {
+        if (lens[ix] == 0)
+            continue;
+        uint64_t shift = s - lens[ix];
+        uint64_t key = shift >= 64 ? codes[ix] : codes[ix] << shift;
+        ents.push_back({key, (uint8_t)ix, (uint8_t)lens[ix]});
+    }
+    std::stable_sort(ents.begin(), ents.end(),
+                     [](const Ent &a, const Ent &b) { return a.key < b.key; });
+    uint64_t k = 0;
+    for (size_t i = 0; i < ents.size(); ++i) {
+        if (i + 1 < ents.size() && ents[i + 1].key == ents[i].key)
+            continue; // the highest symbol index with this key wins
+        keys[k] = ents[i].key;
+        syms[k] = ents[i].sym;
+        klens[k] = ents[i].len;
+        ++k;
+    }
+    *m = k;
+    return HF_OK;
+}
+
+// Index of the largest key <= v, or -1.  This is the reference's
+// `rank1(v + 1) - 1` over the key bit vector (src/huffman/decode/mod.rs:92)
+// and its BTree variant (:157-165).
+static int64_t predecessor(const uint64_t *keys, uint64_t m, uint64_t v)
+{
+    const uint64_t *p = std::upper_bound(keys, keys + m, v);
+    return (int64_t)(p - keys) - 1;
+}
+
+// Multi-level decode table.
+//
+// Level 1 is indexed by the top W1 bits of the bit window; every further level
+// by the next W2 bits.  A slot whose whole window range has one predecessor
+// key holds that key's (symbol, length) directly; a slot that straddles a key
+// points to a sub-table; slots that cannot be resolved within 32 window bits
+// (or once the pool is full) send the decoder to a binary search over the
+// sorted keys.  Built by range-fill over predecessor semantics, so it answers
+// exactly what the reference's rank lookup answers, prefix free or not.
+int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *klens, uint64_t m,
+                     uint64_t sentinel, DecodeLut *lut)
+{
+    if (m == 0 || sentinel == 0)
+        return HF_ERR_EMPTY;
+    if (sentinel > HF_MAX_SENTINEL)
+        return HF_ERR_UNSUPPORTED;
+    const uint32_t s = (uint32_t)sentinel;
+    const uint32_t w1 = std::min<uint32_t>(HF_LUT_W1, s);
+    lut->w1 = w1;
+    lut->sentinel = s;
+    lut->pool.assign((size_t)1 << w1, 0);
+    lut->n_sub = 0;
+    lut->max_direct_len = 0;
+    lut->needs_search = false;
+
+    struct Job {
+        size_t base;     // pool offset of the table
+        uint64_t prefix; // window bits already consumed (value)
+        uint32_t depth;  // number of window bits already consumed
+        uint32_t width;  // index width of this table
+    };
+    std::vector<Job> jobs;
+    jobs.push_back({0, 0, 0, w1});
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        const Job job = jobs[j];
+        // Only the first `sig` bits of the index are window bits; when the
+        // window ends inside this table the rest of the index is don't-care.
+        const uint32_t sig = std::min(job.width, s - job.depth);
+        const uint32_t rem = s - job.depth - sig; // window bits below this slot
+        for (uint32_t i = 0; i < (1u << job.width); ++i) {
+            const uint64_t part = i >> (job.width - sig);
+            const uint64_t lo = ((job.prefix << sig) | part) << rem;
+            const uint64_t hi = lo + (((uint64_t)1 << rem) - 1);
+            const int64_t plo = predecessor(keys, m, lo);
+            const int64_t phi = predecessor(keys, m, hi);
+            uint16_t e;
+            if (phi < 0) {
+                e = HF_LUT_INVALID;
+            } else if (plo == phi && klens[plo] <= 32) {
+                e = (uint16_t)(syms[plo] | ((uint16_t)klens[plo] << 8));
+                lut->max_direct_len = std::max<uint32_t>(lut->max_direct_len, klens[plo]);
+            } else if (plo != phi && job.depth + job.width + HF_LUT_W2 <= 32 &&
+                       lut->n_sub < HF_LUT_MAX_SUB) {
+                // sub-table entries repeat when (i & low bits) differ only in
+                // don't-care bits; that cannot happen here because rem > 0.
+                e = (uint16_t)(0x8000u | lut->n_sub);
+                jobs.push_back({lut->pool.size(), (job.prefix << sig) | part, job.depth + sig,
+                                HF_LUT_W2});
+                lut->pool.resize(lut->pool.size() + ((size_t)1 << HF_LUT_W2), 0);
+                lut->n_sub += 1;
+            } else {
+                e = HF_LUT_SEARCH;
+                lut->needs_search = true;
+            }
+            lut->pool[job.base + i] = e;
+        }
+    }
+    return HF_OK;
+}
+
+} // namespace hf
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+int hf_codeword_lengths_inplace(uint64_t *weights, uint64_t n)
+{
+    if (!weights && n)
+        return HF_ERR_BAD_ARG;
+    return hf::code_lengths_sorted(weights, n);
+}
+
+int hf_sort_by_value(const uint64_t *store, uint64_t n, uint64_t *idx, uint64_t *cnt, uint64_t *m)
+{
+    if (!store || !idx || !cnt || !m)
+        return HF_ERR_BAD_ARG;
+    return hf::sort_nonzero_desc(store, n, idx, cnt, m);
+}
+
+int hf_codewords_from_lengths(const uint64_t *lengths, uint64_t n, uint64_t *small_codes,
+                              uint64_t *big_codes)
+{
+    if (!lengths || !small_codes || !big_codes)
+        return HF_ERR_BAD_ARG;
+    return hf::canonical_codes(lengths, n, small_codes, big_codes);
+}
+
+int hf_build_codebook(const uint64_t *hist, uint64_t n, uint64_t codes[256], uint64_t lens[256])
+{
+    if (!hist || !codes || !lens)
+        return HF_ERR_BAD_ARG;
+    return hf::build_codebook(hist, n, codes, lens);
+}
+
+uint64_t hf_model_sentinel(const uint64_t lens[256]) { return hf::sentinel_of(lens); }
+
+int hf_model_to_table(const uint64_t codes[256], const uint64_t lens[256], uint64_t keys[256],
+                      uint8_t syms[256], uint8_t klens[256], uint64_t *m)
+{
+    if (!codes || !lens || !keys || !syms || !klens || !m)
+        return HF_ERR_BAD_ARG;
+    return hf::model_table(codes, lens, keys, syms, klens, m);
+}
+
+uint64_t hf_calculate_length(uint64_t val)
+{
+    // src/huffman/encode.rs:140-149: bit length, with 0 and 1 both costing one bit
+    return val <= 1 ? 1 : 64 - (uint64_t)__builtin_clzll(val);
+}
+
+} // extern "C"

@@ -1,0 +1,1554 @@
+// hfgpu: HIP kernels (gfx950 / CDNA4, wave64) and the C ABI around them.
+//
+// Everything here is HBM-bound byte/bit work: no matrix cores.  The design
+// rules are coalesced 16-byte global accesses, conflict-free LDS layouts, one
+// pass over the input where the data flow allows it, and enough workgroups in
+// flight (>> 256 CUs) to cover HBM latency.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "hfgpu.h"
+#include "hfgpu_internal.h"
+
+namespace {
+
+// ----------------------------------------------------------------- helpers
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d)
+            v += t;
+    }
+    return v;
+}
+
+// Exclusive scan over a 256-thread workgroup.  s_wave needs 4 words and must
+// not be reused by the caller before the next __syncthreads().
+__device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *s_wave, uint32_t &total)
+{
+    const uint32_t incl = wave_incl_scan(v);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (lane == 63)
+        s_wave[wv] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t x = s_wave[i];
+        woff += i < wv ? x : 0u;
+        tot += x;
+    }
+    total = tot;
+    return woff + incl - v;
+}
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// ---------------------------------------------------------------- histogram
+//
+// One LDS histogram per workgroup laid out [bin][32 columns]: a lane only ever
+// touches column (lane & 31), i.e. its own LDS bank, so a wave's 64 atomic adds
+// are bank-conflict free whatever the data looks like (lanes l and l+32 share
+// a column but are served in different halves of the instruction).  Skewed
+// inputs, where one bin takes most of the increments, therefore run at the
+// same rate as uniform ones.  Columns are summed and merged into the global
+// bins with one 64-bit atomic per bin and workgroup.
+
+constexpr int HIST_THREADS = 512;
+constexpr int HIST_COLS = 32;
+constexpr int HIST_UNROLL = 4; // 16-byte vectors in flight per lane
+
+__device__ __forceinline__ void hist_add4(uint32_t *col, uint32_t v)
+{
+    __hip_atomic_fetch_add(col + ((v & 0xffu) << 5), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(col + (((v >> 8) & 0xffu) << 5), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(col + (((v >> 16) & 0xffu) << 5), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(col + ((v >> 24) << 5), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const uint8_t *__restrict__ in,
+                                                            uint64_t n,
+                                                            unsigned long long *__restrict__ hist)
+{
+    __shared__ uint32_t bins[256 * HIST_COLS];
+    for (uint32_t i = threadIdx.x; i < 256 * HIST_COLS; i += HIST_THREADS)
+        bins[i] = 0;
+    __syncthreads();
+    uint32_t *col = bins + (threadIdx.x & (HIST_COLS - 1));
+
+    // bytes before the first 16-byte boundary and after the last whole vector
+    const uint64_t mis = (16 - ((uintptr_t)in & 15)) & 15;
+    const uint64_t head = mis < n ? mis : n;
+    const uint64_t nvec = (n - head) >> 4;
+    const uint64_t tail = head + (nvec << 4);
+    if (blockIdx.x == 0) {
+        for (uint64_t i = threadIdx.x; i < head; i += HIST_THREADS)
+            __hip_atomic_fetch_add(col + ((uint32_t)in[i] << 5), 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (uint64_t i = tail + threadIdx.x; i < n; i += HIST_THREADS)
+            __hip_atomic_fetch_add(col + ((uint32_t)in[i] << 5), 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
+    const uint4 *vin = reinterpret_cast<const uint4 *>(in + head);
+    const uint64_t stride = (uint64_t)gridDim.x * HIST_THREADS;
+    uint64_t v = (uint64_t)blockIdx.x * HIST_THREADS + threadIdx.x;
+    for (; v + (HIST_UNROLL - 1) * stride < nvec; v += HIST_UNROLL * stride) {
+        uint4 x[HIST_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HIST_UNROLL; ++u)
+            x[u] = vin[v + u * stride];
+#pragma unroll
+        for (int u = 0; u < HIST_UNROLL; ++u) {
+            hist_add4(col, x[u].x);
+            hist_add4(col, x[u].y);
+            hist_add4(col, x[u].z);
+            hist_add4(col, x[u].w);
+        }
+    }
+    for (; v < nvec; v += stride) {
+        const uint4 x = vin[v];
+        hist_add4(col, x.x);
+        hist_add4(col, x.y);
+        hist_add4(col, x.z);
+        hist_add4(col, x.w);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < HIST_COLS; ++i) // rotate so the 32 lanes of a group hit 32 banks
+            s += bins[threadIdx.x * HIST_COLS + ((i + threadIdx.x) & (HIST_COLS - 1))];
+        if (s)
+            atomicAdd(&hist[threadIdx.x], (unsigned long long)s);
+    }
+}
+
+// ------------------------------------------------------------------- encode
+//
+// A tile is 16384 consecutive symbols; a 256-thread workgroup encodes one
+// tile, each thread a run of 64 consecutive symbols (four 16-byte loads).
+//   1. per-thread bit total from an LDS length table, workgroup scan
+//      -> bit offset of every thread inside the tile (+ the chunk lengths of
+//      the gap array);
+//   2. start bit of the tile in the stream: either read from a scanned array
+//      (three-kernel mode) or obtained inside the same launch by a chained
+//      scan with decoupled look-back over 8-byte {status,value} descriptors;
+//   3. every thread streams its codes MSB-first through a 64-bit accumulator
+//      and ORs finished 32-bit words into an LDS image of the tile's stream
+//      words (the image is aligned to the stream's 32-bit words);
+//   4. the image is copied out with coalesced, byte-swapped dword stores.
+// Stream words are owned by the tile that contains their first bit, so every
+// output word is written exactly once with a plain store: a tile completes
+// its last word by encoding up to 31 bits of the symbols that follow it and
+// skips the leading word it shares with its predecessor.
+
+constexpr int ENC_THREADS = 256;
+constexpr int ENC_SPT = 64;
+constexpr int ENC_TILE = ENC_THREADS * ENC_SPT; // 16384 symbols
+constexpr int ENC_WINW = 5120;                  // words of stream image per pass (20 KiB)
+
+constexpr unsigned long long DESC_AGG = 1ull << 62;  // tile total published
+constexpr unsigned long long DESC_INCL = 2ull << 62; // inclusive prefix published
+constexpr unsigned long long DESC_VAL = (1ull << 62) - 1;
+
+struct EncParams {
+    const uint8_t *in;
+    uint64_t n;
+    const uint64_t *tab;   // 256 x (code << 6 | len)
+    const uint8_t *lentab; // 256 x len
+    uint8_t *out;
+    uint64_t out_cap;
+    uint32_t lead_bits;
+    uint32_t aligned16; // input base is 16-byte aligned
+    uint32_t wide;      // some code is longer than 32 bits
+    uint32_t chunk_syms;
+    uint16_t *chunk_bits;
+    uint64_t *seg_off;
+    uint64_t n_chunks;
+    uint64_t *result;
+    uint64_t *tile_off;       // three-kernel mode: exclusive bit offsets per tile
+    unsigned long long *desc; // chained mode: per-tile descriptors (zeroed)
+    uint32_t *ticket;         // chained mode: tile counter (zeroed)
+    uint32_t *abort_flag;     // chained mode: set when a wait expired
+    uint64_t timeout_ticks;   // in 100 MHz wall-clock ticks
+    uint32_t n_tiles;
+};
+
+template <bool FULL>
+__device__ __forceinline__ void enc_load(const uint8_t *__restrict__ in, uint64_t base,
+                                         uint32_t vcnt, uint32_t raw[16])
+{
+    if (FULL) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = p[q];
+            raw[4 * q + 0] = v.x;
+            raw[4 * q + 1] = v.y;
+            raw[4 * q + 2] = v.z;
+            raw[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            raw[k] = 0;
+#pragma unroll
+        for (int k = 0; k < ENC_SPT; ++k)
+            if ((uint32_t)k < vcnt)
+                raw[k >> 2] |= (uint32_t)in[base + k] << (8 * (k & 3));
+    }
+}
+
+template <bool FULL>
+__device__ __forceinline__ uint32_t enc_sum_lens(const uint32_t raw[16], uint32_t vcnt,
+                                                 const uint8_t *s_len)
+{
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < ENC_SPT; ++k) {
+        const uint32_t sym = (raw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        const uint32_t l = s_len[sym];
+        sum += (FULL || (uint32_t)k < vcnt) ? l : 0u;
+    }
+    return sum;
+}
+
+// OR `len` bits of `code` into the stream image at image bit `bitpos`.
+__device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos, uint64_t code,
+                                            uint32_t len, uint32_t wlo, uint32_t whi)
+{
+    while (len > 0) {
+        const uint32_t w = bitpos >> 5, o = bitpos & 31u;
+        const uint32_t take = min(32u - o, len);
+        const uint32_t part = (uint32_t)(code >> (len - take)) & (take == 32 ? ~0u : ((1u << take) - 1u));
+        if (w >= wlo && w < whi)
+            __hip_atomic_fetch_or(stg + (w - wlo), part << (32u - o - take), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        bitpos += take;
+        len -= take;
+    }
+}
+
+template <bool FULL, bool WIDE>
+__device__ __forceinline__ void enc_pack_thread(const uint32_t raw[16], uint32_t vcnt,
+                                                const uint64_t *s_tab, uint32_t *stg,
+                                                uint32_t bitpos, uint32_t nbits, uint32_t wlo,
+                                                uint32_t whi)
+{
+    if (nbits == 0)
+        return;
+    if (((bitpos + nbits - 1) >> 5) < wlo || (bitpos >> 5) >= whi)
+        return;
+    uint32_t w = bitpos >> 5;
+    uint32_t nb = bitpos & 31u; // bits already occupied in word w (by earlier threads)
+    uint64_t acc = 0;           // pending bits, right aligned; bits above nb are stale
+    auto emit = [&](uint32_t val) {
+        if (w >= wlo && w < whi)
+            __hip_atomic_fetch_or(stg + (w - wlo), val, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++w;
+    };
+    auto append = [&](uint32_t code, uint32_t len) { // len <= 32, nb < 32
+        acc = (acc << len) | code;
+        nb += len;
+        if (nb >= 32) {
+            nb -= 32;
+            emit((uint32_t)(acc >> nb));
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < ENC_SPT; ++k) {
+        if (!FULL && (uint32_t)k >= vcnt)
+            break;
+        const uint32_t sym = (raw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        const uint64_t e = s_tab[sym];
+        const uint32_t len = (uint32_t)e & 63u;
+        if (WIDE) {
+            const uint64_t code = e >> 6;
+            if (len > 32) {
+                append((uint32_t)(code >> 32), len - 32);
+                append((uint32_t)code, 32);
+            } else {
+                append((uint32_t)code, len);
+            }
+        } else {
+            append((uint32_t)(e >> 6), len);
+        }
+    }
+    if (nb > 0)
+        emit((uint32_t)(acc << (32 - nb)));
+}
+
+// Bits of the symbols that follow the tile, up to `need` (< 32) of them, so
+// that the tile's last stream word is complete.  Run by wave 0.  Returns the
+// number of bits that were available (capped once it reaches `need`): fewer
+// than `need` means the input ends inside this tile's last word.
+__device__ __forceinline__ uint32_t enc_lookahead(const EncParams &p, uint64_t tile_end,
+                                                  const uint64_t *s_tab, uint32_t *stg,
+                                                  uint32_t endbit, uint32_t need, uint32_t wlo,
+                                                  uint32_t whi)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t idx = tile_end + lane;
+    const uint64_t e = idx < p.n ? s_tab[p.in[idx]] : 0;
+    const uint32_t len = (uint32_t)e & 63u;
+    const uint32_t incl = wave_incl_scan(len);
+    const uint32_t off = incl - len;
+    if (len && off < need)
+        enc_or_bits(stg, endbit + off, e >> 6, len, wlo, whi);
+    uint32_t have = __shfl(incl, 63, 64);
+    if (have < need && tile_end + 64 < p.n) {
+        // only reachable when the data holds symbols whose code length is 0
+        if (lane == 0) {
+            for (uint64_t i = tile_end + 64; i < p.n && have < need; ++i) {
+                const uint64_t e2 = s_tab[p.in[i]];
+                const uint32_t l2 = (uint32_t)e2 & 63u;
+                if (l2)
+                    enc_or_bits(stg, endbit + have, e2 >> 6, l2, wlo, whi);
+                have += l2;
+            }
+        }
+        have = __shfl(have, 0, 64);
+    }
+    return have;
+}
+
+__device__ __forceinline__ void enc_stage_tables(const EncParams &p, uint64_t *s_tab, uint8_t *s_len)
+{
+    s_tab[threadIdx.x] = p.tab[threadIdx.x];
+    s_len[threadIdx.x] = p.lentab[threadIdx.x];
+}
+
+// Three-kernel mode, kernel 1: bit total of every tile.
+__global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
+{
+    __shared__ uint8_t s_len[256];
+    __shared__ uint32_t s_wave[4];
+    s_len[threadIdx.x] = p.lentab[threadIdx.x];
+    __syncthreads();
+    const uint32_t tile = blockIdx.x;
+    const uint64_t base = (uint64_t)tile * ENC_TILE;
+    const uint64_t left = p.n - base;
+    const uint32_t nsym = left < ENC_TILE ? (uint32_t)left : ENC_TILE;
+    const uint32_t t0 = threadIdx.x * ENC_SPT;
+    const uint32_t vcnt = nsym > t0 ? min(nsym - t0, (uint32_t)ENC_SPT) : 0u;
+    uint32_t raw[16];
+    uint32_t sum;
+    if (nsym == ENC_TILE && p.aligned16) {
+        enc_load<true>(p.in, base + t0, vcnt, raw);
+        sum = enc_sum_lens<true>(raw, vcnt, s_len);
+    } else {
+        enc_load<false>(p.in, base + t0, vcnt, raw);
+        sum = enc_sum_lens<false>(raw, vcnt, s_len);
+    }
+    uint32_t total;
+    block_excl_scan256(sum, s_wave, total);
+    if (threadIdx.x == 0)
+        p.tile_off[tile] = total;
+}
+
+// Three-kernel mode, kernel 2: in-place exclusive scan of the tile totals by
+// one workgroup; the grand total lands in tile_off[n] and result[0].
+__global__ __launch_bounds__(256) void enc_scan_tiles_kernel(uint64_t *tile_off, uint32_t n,
+                                                             uint64_t *result)
+{
+    __shared__ uint64_t s_part[256];
+    __shared__ uint64_t s_carry;
+    if (threadIdx.x == 0)
+        s_carry = 0;
+    __syncthreads();
+    constexpr uint32_t PER = 16;
+    for (uint32_t base = 0; base < n; base += 256 * PER) {
+        const uint32_t i0 = base + threadIdx.x * PER;
+        uint64_t v[PER];
+        uint64_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            v[k] = (i0 + k < n) ? tile_off[i0 + k] : 0;
+            sum += v[k];
+        }
+        s_part[threadIdx.x] = sum;
+        __syncthreads();
+        // Hillis-Steele over 256 partial sums
+        for (uint32_t d = 1; d < 256; d <<= 1) {
+            uint64_t t = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint64_t run = s_carry + s_part[threadIdx.x] - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            if (i0 + k < n)
+                tile_off[i0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255)
+            s_carry += s_part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tile_off[n] = s_carry;
+        result[HF_RES_TOTAL_BITS] = s_carry;
+    }
+}
+
+// Decoupled look-back, run by wave 0: exclusive bit prefix of `tile`.
+// Descriptors are single 8-byte words written and read with agent-scope
+// atomics (write-through / L1-bypassing), so the value is its own flag and no
+// other data is handed between workgroups.  Tiles are numbered by a ticket
+// taken at workgroup start, so every predecessor of a waiting tile belongs to
+// a workgroup that is already running; waits are bounded by a wall clock.
+__device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, uint64_t &excl)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t sum = 0;
+    int64_t j = (int64_t)tile - 1;
+    const uint64_t t_start = wall_clock64();
+    while (true) {
+        const int64_t idx = j - (int64_t)lane;
+        unsigned long long d;
+        uint32_t spins = 0;
+        while (true) {
+            d = idx >= 0 ? __hip_atomic_load(p.desc + idx, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT)
+                         : DESC_INCL; // virtual tile -1: inclusive prefix 0
+            if (__all((d >> 62) != 0))
+                break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 63u) == 0) {
+                const bool expired = wall_clock64() - t_start > p.timeout_ticks;
+                const bool aborted = __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (expired || aborted) {
+                    if (lane == 0) {
+                        __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
+                                 (unsigned long long)HF_FLAG_TIMEOUT);
+                    }
+                    excl = 0;
+                    return false;
+                }
+            }
+        }
+        const unsigned long long incl_mask = __ballot((d >> 62) == 2);
+        const uint32_t first = incl_mask ? (uint32_t)__ffsll((long long)incl_mask) - 1u : 64u;
+        uint64_t v = lane <= first ? (d & DESC_VAL) : 0;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1)
+            v += __shfl_xor(v, s, 64);
+        sum += v;
+        if (incl_mask)
+            break;
+        j -= 64;
+    }
+    excl = sum;
+    return true;
+}
+
+template <bool CHAINED>
+__global__ __launch_bounds__(ENC_THREADS) void enc_pack_kernel(EncParams p)
+{
+    __shared__ uint64_t s_tab[256];
+    __shared__ uint8_t s_len[256];
+    __shared__ uint32_t s_toff[ENC_THREADS + 1];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_tile;
+    __shared__ uint64_t s_start;
+    __shared__ uint32_t s_ok;
+    __shared__ uint32_t s_have;
+    __shared__ uint32_t stg[ENC_WINW];
+
+    enc_stage_tables(p, s_tab, s_len);
+    if (CHAINED) {
+        if (threadIdx.x == 0)
+            s_tile = atomicAdd(p.ticket, 1u);
+    }
+    __syncthreads();
+    const uint32_t tile = CHAINED ? s_tile : blockIdx.x;
+    if (tile >= p.n_tiles)
+        return;
+
+    const uint64_t base = (uint64_t)tile * ENC_TILE;
+    const uint64_t left = p.n - base;
+    const uint32_t nsym = left < ENC_TILE ? (uint32_t)left : ENC_TILE;
+    const uint64_t tile_end = base + nsym;
+    const uint32_t t0 = threadIdx.x * ENC_SPT;
+    const uint32_t vcnt = nsym > t0 ? min(nsym - t0, (uint32_t)ENC_SPT) : 0u;
+    const bool full = nsym == ENC_TILE && p.aligned16;
+
+    uint32_t raw[16];
+    uint32_t nbits;
+    if (full) {
+        enc_load<true>(p.in, base + t0, vcnt, raw);
+        nbits = enc_sum_lens<true>(raw, vcnt, s_len);
+    } else {
+        enc_load<false>(p.in, base + t0, vcnt, raw);
+        nbits = enc_sum_lens<false>(raw, vcnt, s_len);
+    }
+    uint32_t tile_bits;
+    const uint32_t toff = block_excl_scan256(nbits, s_wave, tile_bits);
+    s_toff[threadIdx.x] = toff;
+    if (threadIdx.x == 0)
+        s_toff[ENC_THREADS] = tile_bits;
+
+    // start bit of the tile in the stream (lead bits included)
+    if (CHAINED) {
+        if (threadIdx.x < 64) {
+            uint64_t excl = 0;
+            bool ok = true;
+            if (tile == 0) {
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(p.desc, DESC_INCL | (unsigned long long)tile_bits,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(p.desc + tile, DESC_AGG | (unsigned long long)tile_bits,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = enc_lookback(p, tile, excl);
+                if (ok && threadIdx.x == 0)
+                    __hip_atomic_store(p.desc + tile,
+                                       DESC_INCL | (unsigned long long)(excl + tile_bits),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (threadIdx.x == 0) {
+                s_start = excl + p.lead_bits;
+                s_ok = ok ? 1u : 0u;
+            }
+        }
+    } else {
+        if (threadIdx.x == 0) {
+            s_start = p.tile_off[tile] + p.lead_bits;
+            s_ok = 1u;
+        }
+    }
+    __syncthreads();
+    if (!s_ok)
+        return; // a wait expired: the host reports HF_ERR_INTERNAL
+    const uint64_t S = s_start;
+    const uint64_t E = S + tile_bits;
+
+    // gap array: bit length of every chunk, start bit of every segment
+    if (p.chunk_bits) {
+        const uint32_t cpt = p.chunk_syms / ENC_SPT;  // threads per chunk
+        const uint32_t cit = ENC_THREADS / cpt;       // chunks per tile
+        if (threadIdx.x < cit) {
+            const uint64_t c = (uint64_t)tile * cit + threadIdx.x;
+            if (c < p.n_chunks) {
+                const uint32_t b0 = s_toff[threadIdx.x * cpt];
+                const uint32_t b1 = s_toff[(threadIdx.x + 1) * cpt];
+                p.chunk_bits[c] = (uint16_t)(b1 - b0);
+                if ((c % HF_SEG_CHUNKS) == 0)
+                    p.seg_off[c / HF_SEG_CHUNKS] = S + b0;
+            }
+        }
+    }
+    if (tile_end == p.n && threadIdx.x == 0)
+        p.result[HF_RES_TOTAL_BITS] = E - p.lead_bits;
+
+    // stream words [g0, g1) belong to this tile
+    const uint64_t gbase = S >> 5;
+    const uint64_t g0 = tile == 0 ? 0 : (S + 31) >> 5;
+    const uint64_t g1 = (E + 31) >> 5;
+    if (g1 <= g0)
+        return;
+    const uint32_t s_lo = (uint32_t)(S & 31u);
+    const uint32_t endbit = s_lo + tile_bits;
+    const uint32_t need = (32u - (endbit & 31u)) & 31u;
+    const uint32_t nwords = (uint32_t)(g1 - gbase);
+    const bool wide = p.wide != 0;
+
+    for (uint32_t wlo = 0; wlo < nwords; wlo += ENC_WINW) {
+        const uint32_t whi = wlo + ENC_WINW;
+        const uint32_t nz = min((uint32_t)ENC_WINW, nwords - wlo);
+        for (uint32_t i = threadIdx.x; i < nz; i += ENC_THREADS)
+            stg[i] = 0;
+        __syncthreads();
+        if (full) {
+            if (wide)
+                enc_pack_thread<true, true>(raw, vcnt, s_tab, stg, s_lo + toff, nbits, wlo, whi);
+            else
+                enc_pack_thread<true, false>(raw, vcnt, s_tab, stg, s_lo + toff, nbits, wlo, whi);
+        } else {
+            enc_pack_thread<false, true>(raw, vcnt, s_tab, stg, s_lo + toff, nbits, wlo, whi);
+        }
+        if (threadIdx.x < 64 && nwords - 1 >= wlo && nwords - 1 < whi) {
+            const uint32_t have =
+                need ? enc_lookahead(p, tile_end, s_tab, stg, endbit, need, wlo, whi) : 0u;
+            if (threadIdx.x == 0)
+                s_have = have;
+        }
+        __syncthreads();
+        // the stream ends inside this tile's last word when fewer than `need`
+        // bits follow the tile: only its leading bytes exist then
+        const uint64_t limit =
+            (need && nwords - 1 < whi && s_have < need) ? (E + s_have + 7) >> 3 : ~0ull;
+        const uint64_t ga = max(g0, gbase + wlo);
+        const uint64_t gb = min(g1, gbase + whi);
+        for (uint64_t g = ga + threadIdx.x; g < gb; g += ENC_THREADS) {
+            const uint32_t val = bswap32(stg[(uint32_t)(g - gbase) - wlo]);
+            const uint64_t b = g << 2;
+            if (b + 4 <= limit && b + 4 <= p.out_cap) {
+                *reinterpret_cast<uint32_t *>(p.out + b) = val;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (b + i < limit) {
+                        if (b + i < p.out_cap)
+                            p.out[b + i] = (uint8_t)(val >> (8 * i));
+                        else
+                            atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
+                                     (unsigned long long)HF_FLAG_CAPACITY);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------- decode
+//
+// One workgroup decodes one segment = 256 chunks; lane l decodes chunk l
+// (chunk_syms symbols) sequentially.  The chunk start bits come from the gap
+// array: the segment's absolute start plus a workgroup scan of the 16-bit
+// chunk lengths.  The segment's compressed words are staged once, coalesced
+// and byte-swapped, into LDS, and the decoded bytes are collected in a padded
+// LDS image and written out with coalesced 16-byte stores, so global memory
+// only sees whole-line traffic although every lane walks its own bit stream.
+// Symbols are resolved through the LDS-resident multi-level table; the rare
+// slots that the table cannot resolve fall back to a predecessor search over
+// the sorted keys with the full sentinel-wide window.
+
+constexpr int DEC_THREADS = 256;
+
+struct DecParams {
+    const uint8_t *in;
+    uint64_t in_bytes;
+    uint64_t bit_base;
+    uint64_t n_out;
+    uint64_t n_chunks;
+    uint32_t chunk_syms;
+    const uint16_t *chunk_bits;
+    const uint64_t *seg_off;
+    uint8_t *out;
+    uint64_t *result;
+    const uint16_t *lut;
+    uint32_t lut_entries;
+    uint32_t w1;
+    uint32_t sentinel;
+    const uint64_t *keys;
+    const uint8_t *ksyms;
+    const uint8_t *klens;
+    uint32_t m;
+    uint32_t istg_words;
+    uint32_t out_aligned16;
+};
+
+// Big-endian 32-bit word `w` of the compressed buffer; bytes past the end are 0.
+__device__ __forceinline__ uint32_t dec_load_word(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                  uint64_t w)
+{
+    const uint64_t b = w << 2;
+    if (b + 4 <= in_bytes)
+        return bswap32(*reinterpret_cast<const uint32_t *>(in + b));
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (b + i < in_bytes)
+            v |= (uint32_t)in[b + i] << (24 - 8 * i);
+    return v;
+}
+
+struct LdsWords {
+    const uint32_t *w;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return w[i]; }
+};
+struct GlobalWords {
+    const uint8_t *in;
+    uint64_t in_bytes;
+    uint64_t wbase;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const
+    {
+        return dec_load_word(in, in_bytes, wbase + i);
+    }
+};
+
+// Largest key <= v among the sorted keys, or -1.
+__device__ __forceinline__ int dec_predecessor(const uint64_t *keys, uint32_t m, uint64_t v)
+{
+    int lo = 0, hi = (int)m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] <= v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo - 1;
+}
+
+template <typename Src>
+__device__ __forceinline__ uint64_t dec_peek64(const Src &src, uint32_t pos)
+{
+    const uint32_t w = pos >> 5, o = pos & 31u;
+    const uint64_t hi = ((uint64_t)src(w) << 32) | src(w + 1);
+    return o ? (hi << o) | ((uint64_t)src(w + 2) >> (32 - o)) : hi;
+}
+
+template <typename Src>
+struct BitReader {
+    const Src &src;
+    uint64_t buf;  // unread bits, left aligned, zeros below
+    int32_t bits;  // number of valid bits in buf
+    uint32_t wp;   // next word to fetch
+    __device__ __forceinline__ BitReader(const Src &s, uint32_t pos) : src(s) { seek(pos); }
+    __device__ __forceinline__ void seek(uint32_t pos)
+    {
+        const uint32_t w = pos >> 5, o = pos & 31u;
+        buf = (((uint64_t)src(w) << 32) | src(w + 1)) << o;
+        bits = 64 - (int32_t)o;
+        wp = w + 2;
+    }
+    __device__ __forceinline__ uint32_t pos() const { return wp * 32u - (uint32_t)bits; }
+    __device__ __forceinline__ void refill()
+    {
+        if (bits <= 32) {
+            buf |= (uint64_t)src(wp) << (32 - bits);
+            bits += 32;
+            ++wp;
+        }
+    }
+};
+
+// One symbol.  Needs >= 32 valid bits (or >= sentinel bits when the model's
+// sentinel is <= 16) in the reader.
+template <typename Src>
+__device__ __forceinline__ uint32_t dec_symbol(BitReader<Src> &br, const uint16_t *s_lut,
+                                               const DecParams &p, bool &bad)
+{
+    const uint32_t hi = (uint32_t)(br.buf >> 32);
+    uint32_t e = s_lut[hi >> (32 - p.w1)];
+    if (__builtin_expect(e & 0x8000u, 0)) {
+        uint32_t used = p.w1;
+        while ((e & 0x8000u) && e < HF_LUT_INVALID) {
+            const uint32_t idx = (hi << used) >> (32 - HF_LUT_W2);
+            e = s_lut[(1u << p.w1) + ((e & 0x7fffu) << HF_LUT_W2) + idx];
+            used += HF_LUT_W2;
+        }
+        if (e >= HF_LUT_INVALID) {
+            uint32_t sym = 0, len = 0;
+            if (e == HF_LUT_SEARCH) {
+                const uint32_t pos = br.pos();
+                const uint64_t window = dec_peek64(br.src, pos) >> (64 - p.sentinel);
+                const int k = dec_predecessor(p.keys, p.m, window);
+                if (k >= 0) {
+                    sym = p.ksyms[k];
+                    len = p.klens[k];
+                } else {
+                    bad = true;
+                }
+                br.seek(pos + len);
+                br.refill();
+                return sym;
+            }
+            bad = true;
+            return 0;
+        }
+    }
+    const uint32_t len = e >> 8;
+    br.buf <<= len;
+    br.bits -= (int32_t)len;
+    return e & 0xffu;
+}
+
+template <typename Src, int SPR>
+__device__ __forceinline__ void dec_lane(const Src &src, uint32_t startbit, uint32_t cnt,
+                                         const uint16_t *s_lut, const DecParams &p,
+                                         uint32_t *orow, bool &bad)
+{
+    BitReader<Src> br(src, startbit);
+    uint32_t i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+        uint32_t pack = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((k % SPR) == 0)
+                br.refill();
+            pack |= dec_symbol(br, s_lut, p, bad) << (8 * k);
+        }
+        orow[i >> 2] = pack;
+    }
+    if (i < cnt) {
+        uint32_t pack = 0;
+        for (uint32_t k = 0; i + k < cnt; ++k) {
+            br.refill();
+            pack |= dec_symbol(br, s_lut, p, bad) << (8 * k);
+        }
+        orow[i >> 2] = pack;
+    }
+}
+
+template <int SPR>
+__global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t lut_bytes = (p.lut_entries * 2u + 15u) & ~15u;
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *istg = reinterpret_cast<uint32_t *>(smem + lut_bytes);
+    uint32_t *ostg = istg + p.istg_words;
+    const uint32_t cs = p.chunk_syms;
+    const uint32_t orow_words = cs / 4 + 1; // +1: lanes start on different banks
+    uint32_t *s_wave = ostg + HF_SEG_CHUNKS * orow_words;
+
+    const uint64_t seg = blockIdx.x;
+    const uint64_t c = seg * HF_SEG_CHUNKS + threadIdx.x;
+    const bool valid = c < p.n_chunks;
+    const uint32_t cb = valid ? p.chunk_bits[c] : 0u;
+    uint32_t total;
+    const uint32_t excl = block_excl_scan256(cb, s_wave, total);
+    const uint64_t seg_start = p.seg_off[seg] - p.bit_base;
+    const uint64_t wbase = seg_start >> 5;
+    const uint32_t s_lo = (uint32_t)(seg_start & 31u);
+    const uint32_t nw = (s_lo + total + 31u) / 32u + 3u; // +3: readers look up to 64 bits ahead
+    const bool use_lds = nw <= p.istg_words;
+
+    for (uint32_t i = threadIdx.x; i < p.lut_entries; i += DEC_THREADS)
+        s_lut[i] = p.lut[i];
+    if (use_lds)
+        for (uint32_t j = threadIdx.x; j < nw; j += DEC_THREADS)
+            istg[j] = dec_load_word(p.in, p.in_bytes, wbase + j);
+    __syncthreads();
+
+    const uint64_t sym0 = c * cs;
+    const uint32_t cnt = valid ? (uint32_t)min((uint64_t)cs, p.n_out - sym0) : 0u;
+    bool bad = false;
+    if (cnt) {
+        uint32_t *orow = ostg + threadIdx.x * orow_words;
+        if (use_lds) {
+            LdsWords src{istg};
+            dec_lane<LdsWords, SPR>(src, s_lo + excl, cnt, s_lut, p, orow, bad);
+        } else {
+            GlobalWords src{p.in, p.in_bytes, wbase};
+            dec_lane<GlobalWords, SPR>(src, s_lo + excl, cnt, s_lut, p, orow, bad);
+        }
+    }
+    if (bad)
+        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
+    __syncthreads();
+
+    const uint64_t obase = seg * HF_SEG_CHUNKS * (uint64_t)cs;
+    const uint64_t oleft = p.n_out - obase;
+    const uint32_t seg_len = (uint32_t)min(oleft, (uint64_t)HF_SEG_CHUNKS * cs);
+    for (uint32_t o = threadIdx.x * 16u; o < seg_len; o += DEC_THREADS * 16u) {
+        const uint32_t ch = o / cs, within = o % cs;
+        const uint32_t *srcw = ostg + ch * orow_words + within / 4;
+        uint4 v;
+        v.x = srcw[0];
+        v.y = srcw[1];
+        v.z = srcw[2];
+        v.w = srcw[3];
+        if (o + 16u <= seg_len && p.out_aligned16) {
+            *reinterpret_cast<uint4 *>(p.out + obase + o) = v;
+        } else {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t i = 0; i < 16u && o + i < seg_len; ++i)
+                p.out[obase + o + i] = (uint8_t)(vv[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
+// Gap-free decode: one lane walks the whole stream with predecessor search.
+__global__ void dec_serial_kernel(DecParams p)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    uint64_t pos = 0; // may exceed 32 bits: peek relative to the current word
+    bool bad = false;
+    for (uint64_t i = 0; i < p.n_out; ++i) {
+        GlobalWords s2{p.in, p.in_bytes, pos >> 5};
+        const uint64_t window = dec_peek64(s2, (uint32_t)(pos & 31u)) >> (64 - p.sentinel);
+        const int k = dec_predecessor(p.keys, p.m, window);
+        uint32_t len = 0;
+        uint8_t sym = 0;
+        if (k >= 0) {
+            sym = p.ksyms[k];
+            len = p.klens[k];
+        } else {
+            bad = true;
+        }
+        p.out[i] = sym;
+        pos += len;
+    }
+    if (bad)
+        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
+}
+
+// Exact emission schedule of Encoder::write (src/huffman/encode.rs:91-116)
+// for one call: one lane replays put (:57-66) and cleanup (:67-83) over the
+// symbols so that the call's return value and the counters match the
+// reference for small writes.  state = {buffer, remaining_bits, writeout};
+// out = {return value, error (1 = code length above 64)}.
+__global__ void enc_automaton_kernel(const uint8_t *__restrict__ in, uint64_t n,
+                                     const uint64_t *__restrict__ codes,
+                                     const uint64_t *__restrict__ lens, uint64_t *state,
+                                     uint64_t *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    uint64_t buffer = state[0], remaining = state[1], total = state[2];
+    uint64_t emitted = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t code = codes[in[i]], len = lens[in[i]];
+        if (len > 64) {
+            out[1] = 1;
+            break;
+        }
+        while (len > remaining) { // put
+            emitted += 1;
+            buffer <<= 8;
+            remaining += 8;
+        }
+        remaining -= len;
+        buffer += code << (remaining & 63);
+        if (buffer & 0x0000000000FF0000ull) { // cleanup
+            emitted += 5;
+            buffer <<= 40;
+            remaining += 40;
+        }
+    }
+    const uint64_t tz = buffer ? (uint64_t)__builtin_ctzll(buffer) : 64;
+    state[0] = buffer;
+    state[1] = remaining;
+    state[2] = total + emitted;
+    out[0] = emitted + 8 - tz / 8;
+}
+
+} // namespace
+
+// ===================================================================== host
+
+struct hf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    uint64_t *d_result = nullptr; // result block of the synchronous entry points
+    int num_cus = 256;
+    int enc_mode = 1;
+    int hist_grid = 0;
+    int timeout_ms = 2000;
+};
+
+struct hf_model {
+    hf_ctx *ctx = nullptr;
+    void *d_blob = nullptr;
+    uint64_t *d_enc = nullptr; // 256 x (code << 6 | len)
+    uint8_t *d_len = nullptr;
+    uint16_t *d_lut = nullptr;
+    uint64_t *d_keys = nullptr;
+    uint8_t *d_ksyms = nullptr;
+    uint8_t *d_klens = nullptr;
+    uint32_t lut_entries = 0;
+    uint32_t m = 0;
+    uint32_t sentinel = 0;
+    uint32_t w1 = 0;
+    uint32_t maxlen = 0;
+    bool has_encode = false;
+};
+
+namespace {
+
+int fail(hf_ctx *ctx, int status, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+#define HF_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((ctx), HF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+int ensure_scratch(hf_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes)
+        return HF_OK;
+    if (ctx->scratch) {
+        HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        HF_HIP(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    HF_HIP(ctx, hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+    return HF_OK;
+}
+
+int flags_to_status(hf_ctx *ctx, uint64_t flags)
+{
+    if (flags & HF_FLAG_TIMEOUT)
+        return fail(ctx, HF_ERR_INTERNAL, "a device-side inter-workgroup wait expired");
+    if (flags & HF_FLAG_CAPACITY)
+        return fail(ctx, HF_ERR_CAPACITY, "output buffer too small");
+    if (flags & HF_FLAG_DECODE)
+        return fail(ctx, HF_ERR_DECODE, "bit window below the smallest key of the model");
+    return HF_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*257 or null*/,
+                 const uint8_t *len_tab, const hf::DecodeLut &lut, const uint64_t *keys,
+                 const uint8_t *syms, const uint8_t *klens, uint64_t m)
+{
+    const size_t off_enc = 0;
+    const size_t off_len = off_enc + 257 * sizeof(uint64_t);
+    const size_t off_lut = align_up(off_len + 256, 16);
+    const size_t off_keys = align_up(off_lut + lut.pool.size() * 2, 16);
+    const size_t off_ksyms = off_keys + 256 * sizeof(uint64_t);
+    const size_t off_klens = off_ksyms + 256;
+    const size_t total = off_klens + 256;
+    std::vector<uint8_t> blob(total, 0);
+    if (enc_tab) {
+        std::memcpy(blob.data() + off_enc, enc_tab, 257 * sizeof(uint64_t));
+        std::memcpy(blob.data() + off_len, len_tab, 256);
+    }
+    std::memcpy(blob.data() + off_lut, lut.pool.data(), lut.pool.size() * 2);
+    std::memcpy(blob.data() + off_keys, keys, m * sizeof(uint64_t));
+    std::memcpy(blob.data() + off_ksyms, syms, m);
+    std::memcpy(blob.data() + off_klens, klens, m);
+    HF_HIP(ctx, hipMalloc(&mod->d_blob, total));
+    HF_HIP(ctx, hipMemcpy(mod->d_blob, blob.data(), total, hipMemcpyHostToDevice));
+    uint8_t *b = static_cast<uint8_t *>(mod->d_blob);
+    mod->d_enc = reinterpret_cast<uint64_t *>(b + off_enc);
+    mod->d_len = b + off_len;
+    mod->d_lut = reinterpret_cast<uint16_t *>(b + off_lut);
+    mod->d_keys = reinterpret_cast<uint64_t *>(b + off_keys);
+    mod->d_ksyms = b + off_ksyms;
+    mod->d_klens = b + off_klens;
+    mod->lut_entries = (uint32_t)lut.pool.size();
+    mod->m = (uint32_t)m;
+    mod->sentinel = lut.sentinel;
+    mod->w1 = lut.w1;
+    return HF_OK;
+}
+
+bool valid_chunk_syms(uint32_t cs)
+{
+    return cs == 64 || cs == 128 || cs == 256;
+}
+
+} // namespace
+
+extern "C" {
+
+int hf_version(void) { return 1; }
+
+const char *hf_strerror(int status)
+{
+    switch (status) {
+    case HF_OK: return "ok";
+    case HF_ERR_BAD_ARG: return "bad argument";
+    case HF_ERR_CODELEN: return "code length above 64 (InvalidData)";
+    case HF_ERR_EMPTY: return "empty input or model";
+    case HF_ERR_CAPACITY: return "output buffer too small";
+    case HF_ERR_HIP: return "HIP runtime error";
+    case HF_ERR_BAD_CODEBOOK: return "code does not fit its length";
+    case HF_ERR_DECODE: return "bit window below the smallest key";
+    case HF_ERR_INTERNAL: return "device-side wait expired";
+    case HF_ERR_UNSUPPORTED: return "code length or sentinel above 57";
+    default: return "unknown status";
+    }
+}
+
+int hf_ctx_create(int device, hf_ctx **out)
+{
+    if (!out)
+        return HF_ERR_BAD_ARG;
+    *out = nullptr;
+    hf_ctx *ctx = new (std::nothrow) hf_ctx();
+    if (!ctx)
+        return HF_ERR_INTERNAL;
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        delete ctx;
+        return HF_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        ctx->num_cus = prop.multiProcessorCount;
+    e = hipMalloc(reinterpret_cast<void **>(&ctx->d_result), HF_RES_WORDS * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        delete ctx;
+        return HF_ERR_HIP;
+    }
+    *out = ctx;
+    return HF_OK;
+}
+
+int hf_ctx_destroy(hf_ctx *ctx)
+{
+    if (!ctx)
+        return HF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch)
+        (void)hipFree(ctx->scratch);
+    if (ctx->d_result)
+        (void)hipFree(ctx->d_result);
+    delete ctx;
+    return HF_OK;
+}
+
+int hf_ctx_set_stream(hf_ctx *ctx, void *stream)
+{
+    if (!ctx)
+        return HF_ERR_BAD_ARG;
+    ctx->stream = static_cast<hipStream_t>(stream);
+    return HF_OK;
+}
+
+int hf_ctx_synchronize(hf_ctx *ctx)
+{
+    if (!ctx)
+        return HF_ERR_BAD_ARG;
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HF_OK;
+}
+
+const char *hf_last_error(const hf_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name)
+        return HF_ERR_BAD_ARG;
+    if (!std::strcmp(name, "enc_mode") && (value == 0 || value == 1))
+        ctx->enc_mode = (int)value;
+    else if (!std::strcmp(name, "hist_grid") && value >= 0 && value <= 65536)
+        ctx->hist_grid = (int)value;
+    else if (!std::strcmp(name, "timeout_ms") && value > 0 && value <= 60000)
+        ctx->timeout_ms = (int)value;
+    else
+        return fail(ctx, HF_ERR_BAD_ARG, "unknown option or value out of range: %s", name);
+    return HF_OK;
+}
+
+// ---------------------------------------------------------------- histogram
+
+int hf_histogram_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d_hist)
+{
+    if (!ctx || !d_hist || (!d_in && n))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram: null pointer");
+    if (n >= (1ull << 40))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram: n must be below 2^40");
+    HF_HIP(ctx, hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), ctx->stream));
+    if (n == 0)
+        return HF_OK;
+    const uint64_t per_block = (uint64_t)HIST_THREADS * 16 * HIST_UNROLL;
+    uint64_t want = (n + per_block - 1) / per_block;
+    uint64_t cap = ctx->hist_grid > 0 ? (uint64_t)ctx->hist_grid : (uint64_t)ctx->num_cus * 4;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+    hipLaunchKernelGGL(hist_kernel, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, d_in, n,
+                       reinterpret_cast<unsigned long long *>(d_hist));
+    HF_HIP(ctx, hipGetLastError());
+    return HF_OK;
+}
+
+int hf_histogram(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t hist[256])
+{
+    if (!ctx || !hist)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram: null pointer");
+    int rc = ensure_scratch(ctx, 256 * sizeof(uint64_t));
+    if (rc != HF_OK)
+        return rc;
+    uint64_t *d_hist = static_cast<uint64_t *>(ctx->scratch);
+    rc = hf_histogram_async(ctx, d_in, n, d_hist);
+    if (rc != HF_OK)
+        return rc;
+    HF_HIP(ctx, hipMemcpyAsync(hist, d_hist, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HF_OK;
+}
+
+// -------------------------------------------------------------------- model
+
+int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[256],
+                    hf_model **out)
+{
+    if (!ctx || !codes || !lens || !out)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_model_create: null pointer");
+    *out = nullptr;
+    uint64_t maxlen = 0;
+    for (int i = 0; i < 256; ++i) {
+        if (lens[i] > 64)
+            return fail(ctx, HF_ERR_CODELEN, "symbol %d: code length %llu > 64", i,
+                        (unsigned long long)lens[i]);
+        if (lens[i] > HF_MAX_CODELEN)
+            return fail(ctx, HF_ERR_UNSUPPORTED, "symbol %d: code length %llu > %u", i,
+                        (unsigned long long)lens[i], HF_MAX_CODELEN);
+        if (lens[i] < 64 && (codes[i] >> lens[i]) != 0)
+            return fail(ctx, HF_ERR_BAD_CODEBOOK, "symbol %d: code does not fit %llu bits", i,
+                        (unsigned long long)lens[i]);
+        maxlen = std::max(maxlen, lens[i]);
+    }
+    if (maxlen == 0)
+        return fail(ctx, HF_ERR_EMPTY, "model has no symbol with a code");
+    uint64_t enc[257];
+    uint8_t len8[256];
+    for (int i = 0; i < 256; ++i) {
+        enc[i] = (codes[i] << 6) | lens[i];
+        len8[i] = (uint8_t)lens[i];
+    }
+    enc[256] = 0;
+    uint64_t keys[256], m = 0;
+    uint8_t syms[256], klens[256];
+    int rc = hf::model_table(codes, lens, keys, syms, klens, &m);
+    if (rc != HF_OK)
+        return fail(ctx, rc, "hf_model_create: cannot build the key table");
+    hf::DecodeLut lut;
+    rc = hf::build_decode_lut(keys, syms, klens, m, maxlen, &lut);
+    if (rc != HF_OK)
+        return fail(ctx, rc, "hf_model_create: cannot build the decode table");
+    hf_model *mod = new (std::nothrow) hf_model();
+    if (!mod)
+        return HF_ERR_INTERNAL;
+    mod->ctx = ctx;
+    mod->maxlen = (uint32_t)maxlen;
+    mod->has_encode = true;
+    rc = upload_model(ctx, mod, enc, len8, lut, keys, syms, klens, m);
+    if (rc != HF_OK) {
+        delete mod;
+        return rc;
+    }
+    *out = mod;
+    return HF_OK;
+}
+
+int hf_model_from_table(hf_ctx *ctx, const uint64_t *keys, const uint8_t *syms,
+                        const uint8_t *klens, uint64_t m, uint64_t sentinel, hf_model **out)
+{
+    if (!ctx || !keys || !syms || !klens || !out)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_model_from_table: null pointer");
+    *out = nullptr;
+    if (m == 0 || m > 256)
+        return fail(ctx, HF_ERR_EMPTY, "hf_model_from_table: %llu entries", (unsigned long long)m);
+    if (sentinel == 0 || sentinel > HF_MAX_SENTINEL)
+        return fail(ctx, HF_ERR_UNSUPPORTED, "sentinel %llu outside 1..%u",
+                    (unsigned long long)sentinel, HF_MAX_SENTINEL);
+    for (uint64_t i = 0; i < m; ++i) {
+        if (i && keys[i] <= keys[i - 1])
+            return fail(ctx, HF_ERR_BAD_ARG, "keys must be strictly ascending");
+        if (sentinel < 64 && (keys[i] >> sentinel) != 0)
+            return fail(ctx, HF_ERR_BAD_CODEBOOK, "key %llu wider than the sentinel",
+                        (unsigned long long)i);
+        if (klens[i] > HF_MAX_CODELEN)
+            return fail(ctx, HF_ERR_UNSUPPORTED, "entry %llu: length above %u",
+                        (unsigned long long)i, HF_MAX_CODELEN);
+    }
+    hf::DecodeLut lut;
+    int rc = hf::build_decode_lut(keys, syms, klens, m, sentinel, &lut);
+    if (rc != HF_OK)
+        return fail(ctx, rc, "hf_model_from_table: cannot build the decode table");
+    hf_model *mod = new (std::nothrow) hf_model();
+    if (!mod)
+        return HF_ERR_INTERNAL;
+    mod->ctx = ctx;
+    mod->maxlen = (uint32_t)sentinel;
+    mod->has_encode = false;
+    rc = upload_model(ctx, mod, nullptr, nullptr, lut, keys, syms, klens, m);
+    if (rc != HF_OK) {
+        delete mod;
+        return rc;
+    }
+    *out = mod;
+    return HF_OK;
+}
+
+int hf_model_destroy(hf_model *model)
+{
+    if (!model)
+        return HF_OK;
+    if (model->d_blob) {
+        (void)hipSetDevice(model->ctx->device);
+        (void)hipStreamSynchronize(model->ctx->stream);
+        (void)hipFree(model->d_blob);
+    }
+    delete model;
+    return HF_OK;
+}
+
+// ------------------------------------------------------------------- encode
+
+uint64_t hf_encode_bound(const hf_model *model, uint64_t n, uint32_t lead_bits)
+{
+    const uint64_t maxlen = model ? model->maxlen : 64;
+    const uint64_t bytes = (lead_bits + n * maxlen + 7) / 8;
+    return (bytes + 3) & ~3ull; // whole 32-bit words keep every store on the fast path
+}
+
+int hf_gap_layout(uint64_t n, uint32_t chunk_syms, uint64_t *n_chunks, uint64_t *n_segs)
+{
+    if (!valid_chunk_syms(chunk_syms) || !n_chunks || !n_segs)
+        return HF_ERR_BAD_ARG;
+    *n_chunks = (n + chunk_syms - 1) / chunk_syms;
+    *n_segs = (*n_chunks + HF_SEG_CHUNKS - 1) / HF_SEG_CHUNKS;
+    return HF_OK;
+}
+
+int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
+                    uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,
+                    uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint64_t *d_result)
+{
+    if (!ctx || !model || !d_result || (!d_in && n) || (!d_out && out_cap))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: null pointer");
+    if (!model->has_encode)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: model was built for decoding only");
+    if (lead_bits > 7)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: lead_bits must be 0..7");
+    if ((uintptr_t)d_out & 3)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: d_out must be 4-byte aligned");
+    if ((d_chunk_bits == nullptr) != (d_seg_off == nullptr))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: pass both gap arrays or neither");
+    if (d_chunk_bits && !valid_chunk_syms(chunk_syms))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: chunk_syms must be 64, 128 or 256");
+    if (n >= (1ull << 45))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: n too large");
+    HF_HIP(ctx, hipMemsetAsync(d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
+    if (n == 0) {
+        const uint64_t bytes = (lead_bits + 7) / 8;
+        if (bytes > out_cap)
+            return fail(ctx, HF_ERR_CAPACITY, "hf_encode: output buffer too small");
+        if (bytes)
+            HF_HIP(ctx, hipMemsetAsync(d_out, 0, bytes, ctx->stream));
+        return HF_OK;
+    }
+    const uint64_t n_tiles64 = (n + ENC_TILE - 1) / ENC_TILE;
+    const uint32_t n_tiles = (uint32_t)n_tiles64;
+
+    EncParams p{};
+    p.in = d_in;
+    p.n = n;
+    p.tab = model->d_enc;
+    p.lentab = model->d_len;
+    p.out = d_out;
+    p.out_cap = out_cap;
+    p.lead_bits = lead_bits;
+    p.aligned16 = ((uintptr_t)d_in & 15) == 0;
+    p.wide = model->maxlen > 32;
+    p.chunk_syms = d_chunk_bits ? chunk_syms : 64;
+    p.chunk_bits = d_chunk_bits;
+    p.seg_off = d_seg_off;
+    p.n_chunks = d_chunk_bits ? (n + chunk_syms - 1) / chunk_syms : 0;
+    p.result = d_result;
+    p.n_tiles = n_tiles;
+    p.timeout_ticks = (uint64_t)ctx->timeout_ms * 100000ull;
+
+    const size_t need = ((size_t)n_tiles + 4) * sizeof(uint64_t);
+    int rc = ensure_scratch(ctx, need);
+    if (rc != HF_OK)
+        return rc;
+    if (ctx->enc_mode == 0) {
+        p.tile_off = static_cast<uint64_t *>(ctx->scratch);
+        hipLaunchKernelGGL(enc_tile_bits_kernel, dim3(n_tiles), dim3(ENC_THREADS), 0, ctx->stream,
+                           p);
+        hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(256), 0, ctx->stream, p.tile_off,
+                           n_tiles, d_result);
+        hipLaunchKernelGGL(enc_pack_kernel<false>, dim3(n_tiles), dim3(ENC_THREADS), 0,
+                           ctx->stream, p);
+    } else {
+        HF_HIP(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
+        p.desc = static_cast<unsigned long long *>(ctx->scratch);
+        p.ticket = reinterpret_cast<uint32_t *>(p.desc + n_tiles);
+        p.abort_flag = p.ticket + 1;
+        hipLaunchKernelGGL(enc_pack_kernel<true>, dim3(n_tiles), dim3(ENC_THREADS), 0, ctx->stream,
+                           p);
+    }
+    HF_HIP(ctx, hipGetLastError());
+    return HF_OK;
+}
+
+int hf_encode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
+              uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,
+              uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint64_t *total_bits)
+{
+    if (!ctx)
+        return HF_ERR_BAD_ARG;
+    int rc = hf_encode_async(ctx, model, d_in, n, lead_bits, d_out, out_cap, chunk_syms,
+                             d_chunk_bits, d_seg_off, ctx->d_result);
+    if (rc != HF_OK)
+        return rc;
+    uint64_t res[HF_RES_WORDS];
+    HF_HIP(ctx, hipMemcpyAsync(res, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (total_bits)
+        *total_bits = res[HF_RES_TOTAL_BITS];
+    return flags_to_status(ctx, res[HF_RES_FLAGS]);
+}
+
+int hf_encoder_write_value(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, const uint64_t codes[256],
+                           const uint64_t lens[256], uint64_t state[3], uint64_t *ret)
+{
+    if (!ctx || !codes || !lens || !state || !ret || (!d_in && n))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encoder_write_value: null pointer");
+    if (n > HF_WRITE_VALUE_MAX)
+        return fail(ctx, HF_ERR_UNSUPPORTED, "hf_encoder_write_value: more than %llu symbols",
+                    (unsigned long long)HF_WRITE_VALUE_MAX);
+    const size_t bytes = (512 + 3 + 2) * sizeof(uint64_t);
+    int rc = ensure_scratch(ctx, bytes);
+    if (rc != HF_OK)
+        return rc;
+    uint64_t host[512 + 3 + 2];
+    std::memcpy(host, codes, 256 * sizeof(uint64_t));
+    std::memcpy(host + 256, lens, 256 * sizeof(uint64_t));
+    std::memcpy(host + 512, state, 3 * sizeof(uint64_t));
+    host[515] = host[516] = 0;
+    uint64_t *d = static_cast<uint64_t *>(ctx->scratch);
+    HF_HIP(ctx, hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(enc_automaton_kernel, dim3(1), dim3(64), 0, ctx->stream, d_in, n, d, d + 256,
+                       d + 512, d + 515);
+    HF_HIP(ctx, hipGetLastError());
+    HF_HIP(ctx, hipMemcpyAsync(host + 512, d + 512, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (host[516])
+        return fail(ctx, HF_ERR_CODELEN, "Codelen > 64");
+    std::memcpy(state, host + 512, 3 * sizeof(uint64_t));
+    *ret = host[515];
+    return HF_OK;
+}
+
+// ------------------------------------------------------------------- decode
+
+static int fill_dec_params(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in,
+                           uint64_t in_bytes, uint64_t bit_base, uint64_t n_out, uint8_t *d_out,
+                           uint64_t *d_result, DecParams *p)
+{
+    if (!ctx || !model || !d_result || (!d_out && n_out) || (!d_in && in_bytes))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: null pointer");
+    if ((uintptr_t)d_in & 3)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: d_in must be 4-byte aligned");
+    p->in = d_in;
+    p->in_bytes = in_bytes;
+    p->bit_base = bit_base;
+    p->n_out = n_out;
+    p->out = d_out;
+    p->result = d_result;
+    p->lut = model->d_lut;
+    p->lut_entries = model->lut_entries;
+    p->w1 = model->w1;
+    p->sentinel = model->sentinel;
+    p->keys = model->d_keys;
+    p->ksyms = model->d_ksyms;
+    p->klens = model->d_klens;
+    p->m = model->m;
+    p->out_aligned16 = ((uintptr_t)d_out & 15) == 0;
+    return HF_OK;
+}
+
+int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
+                    uint64_t bit_base, uint64_t n_out, uint32_t chunk_syms,
+                    const uint16_t *d_chunk_bits, const uint64_t *d_seg_off, uint8_t *d_out,
+                    uint64_t *d_result)
+{
+    DecParams p{};
+    int rc = fill_dec_params(ctx, model, d_in, in_bytes, bit_base, n_out, d_out, d_result, &p);
+    if (rc != HF_OK)
+        return rc;
+    if (!valid_chunk_syms(chunk_syms))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: chunk_syms must be 64, 128 or 256");
+    if (n_out && (!d_chunk_bits || !d_seg_off))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: gap arrays missing (use hf_decode_serial)");
+    HF_HIP(ctx, hipMemsetAsync(d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
+    if (n_out == 0)
+        return HF_OK;
+    p.chunk_syms = chunk_syms;
+    p.chunk_bits = d_chunk_bits;
+    p.seg_off = d_seg_off;
+    p.n_chunks = (n_out + chunk_syms - 1) / chunk_syms;
+    const uint64_t n_segs = (p.n_chunks + HF_SEG_CHUNKS - 1) / HF_SEG_CHUNKS;
+    // LDS: table + compressed image (sized for 8 bits per symbol; denser
+    // segments read from global memory instead) + padded output image.
+    const uint32_t lut_bytes = (model->lut_entries * 2u + 15u) & ~15u;
+    p.istg_words = HF_SEG_CHUNKS * chunk_syms / 4 + 8;
+    const uint32_t ostg_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
+    const size_t lds = lut_bytes + (size_t)(p.istg_words + ostg_words + 4) * 4;
+    if (lds > 160 * 1024 - 64)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: chunk_syms %u needs %zu bytes of LDS",
+                    chunk_syms, lds);
+    const int spr = model->sentinel <= 8 ? 4 : (model->sentinel <= 16 ? 2 : 1);
+    auto kern = spr == 4 ? dec_kernel<4> : (spr == 2 ? dec_kernel<2> : dec_kernel<1>);
+    HF_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((uint32_t)n_segs), dim3(DEC_THREADS), lds, ctx->stream, p);
+    HF_HIP(ctx, hipGetLastError());
+    return HF_OK;
+}
+
+int hf_decode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
+              uint64_t bit_base, uint64_t n_out, uint32_t chunk_syms,
+              const uint16_t *d_chunk_bits, const uint64_t *d_seg_off, uint8_t *d_out)
+{
+    if (!ctx)
+        return HF_ERR_BAD_ARG;
+    int rc = hf_decode_async(ctx, model, d_in, in_bytes, bit_base, n_out, chunk_syms, d_chunk_bits,
+                             d_seg_off, d_out, ctx->d_result);
+    if (rc != HF_OK)
+        return rc;
+    uint64_t res[HF_RES_WORDS];
+    HF_HIP(ctx, hipMemcpyAsync(res, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return flags_to_status(ctx, res[HF_RES_FLAGS]);
+}
+
+int hf_decode_serial(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
+                     uint64_t bit_base, uint64_t n_out, uint8_t *d_out)
+{
+    if (!ctx)
+        return HF_ERR_BAD_ARG;
+    DecParams p{};
+    int rc = fill_dec_params(ctx, model, d_in, in_bytes, bit_base, n_out, d_out, ctx->d_result, &p);
+    if (rc != HF_OK)
+        return rc;
+    if (bit_base != 0)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_serial: bit_base must be 0");
+    HF_HIP(ctx, hipMemsetAsync(ctx->d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
+    if (n_out) {
+        hipLaunchKernelGGL(dec_serial_kernel, dim3(1), dim3(64), 0, ctx->stream, p);
+        HF_HIP(ctx, hipGetLastError());
+    }
+    uint64_t res[HF_RES_WORDS];
+    HF_HIP(ctx, hipMemcpyAsync(res, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return flags_to_status(ctx, res[HF_RES_FLAGS]);
+}
+
+} // extern "C"

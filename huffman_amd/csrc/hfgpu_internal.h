@@ -1,0 +1,39 @@
+// Shared between the host-side codebook code and the HIP translation unit.
+#ifndef HFGPU_INTERNAL_H
+#define HFGPU_INTERNAL_H
+
+#include <stdint.h>
+#include <vector>
+
+// Decode lookup-table geometry.
+#define HF_LUT_W1 11u          // index bits of the first level
+#define HF_LUT_W2 7u           // index bits of every further level
+#define HF_LUT_MAX_SUB 32u     // sub-tables kept in LDS at most
+#define HF_LUT_SEARCH 0xFFFFu  // entry: resolve by binary search over the keys
+#define HF_LUT_INVALID 0xFFFEu // entry: window below the smallest key
+#define HF_MAX_SENTINEL 57u    // the slice decoder of the reference needs <= 57
+#define HF_MAX_CODELEN 57u     // longest code the encoder packs faithfully
+
+namespace hf {
+
+struct DecodeLut {
+    uint32_t w1 = 0;
+    uint32_t sentinel = 0;
+    uint32_t n_sub = 0;
+    uint32_t max_direct_len = 0;
+    bool needs_search = false;
+    std::vector<uint16_t> pool; // level 1 followed by the sub-tables
+};
+
+int code_lengths_sorted(uint64_t *w, uint64_t n);
+int sort_nonzero_desc(const uint64_t *store, uint64_t n, uint64_t *idx, uint64_t *cnt, uint64_t *m);
+int canonical_codes(const uint64_t *len, uint64_t n, uint64_t *small_codes, uint64_t *big_codes);
+int build_codebook(const uint64_t *hist, uint64_t n, uint64_t codes[256], uint64_t lens[256]);
+uint64_t sentinel_of(const uint64_t lens[256]);
+int model_table(const uint64_t codes[256], const uint64_t lens[256], uint64_t keys[256],
+                uint8_t syms[256], uint8_t klens[256], uint64_t *m);
+int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *klens, uint64_t m,
+                     uint64_t sentinel, DecodeLut *lut);
+
+} // namespace hf
+#endif

@@ -1,0 +1,206 @@
+/*
+ * hfgpu -- MI355X (gfx950) Huffman codec behind a flat C ABI.
+ *
+ * Drop-in boundary for the hot path of the rscompress-huffman crate
+ * (histogram -> host codebook -> encode -> decode).  The reference crate has no
+ * FFI of its own; each entry point below names the public Rust item it
+ * replaces (paths relative to the reference crate root).  Every `usize` of the
+ * reference is a uint64_t here.
+ *
+ * Conventions
+ *   - Every function returns an hf_status (0 = HF_OK); nothing unwinds across
+ *     the ABI.  hf_last_error(ctx) gives a human-readable detail string.
+ *   - Pointers named d_* are DEVICE pointers (HBM of the context's GPU);
+ *     all other pointers are host memory.  Buffers are caller-owned.
+ *   - *_async entry points only enqueue work on the context's stream and
+ *     report device-side conditions through the d_result block; the variants
+ *     without the suffix also synchronise the stream and translate the
+ *     device-side flags into a status.
+ *   - One context per GPU and per host thread; calls on one context must not
+ *     overlap.
+ */
+#ifndef HFGPU_H
+#define HFGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HF_API __attribute__((visibility("default")))
+
+typedef enum hf_status {
+    HF_OK = 0,
+    HF_ERR_BAD_ARG = 1,      /* null pointer, misaligned buffer, bad chunk size */
+    HF_ERR_CODELEN = 2,      /* a code length above 64: io::ErrorKind::InvalidData at
+                                src/huffman/encode.rs:102-104 */
+    HF_ERR_EMPTY = 3,        /* empty histogram / empty model: the reference panics at
+                                src/huffman/mod.rs:72-73 */
+    HF_ERR_CAPACITY = 4,     /* output buffer too small */
+    HF_ERR_HIP = 5,          /* a HIP runtime call failed */
+    HF_ERR_BAD_CODEBOOK = 6, /* code >= 2^len, or a shift of 64 bits in
+                                src/huffman/mod.rs:165-168 */
+    HF_ERR_DECODE = 7,       /* bit window below the smallest key: the reference
+                                underflows and panics at src/huffman/decode/mod.rs:92,189 */
+    HF_ERR_INTERNAL = 8,     /* device-side wait timed out */
+    HF_ERR_UNSUPPORTED = 9   /* code length 58..64 (the reference emits a damaged stream
+                                there) or sentinel above 57 */
+} hf_status;
+
+typedef struct hf_ctx hf_ctx;     /* one GPU + stream + scratch */
+typedef struct hf_model hf_model; /* device-resident codebook + decode tables */
+
+/* Device-side result block written by the *_async calls (4 x uint64_t). */
+enum { HF_RES_TOTAL_BITS = 0, HF_RES_FLAGS = 1, HF_RES_WORDS = 4 };
+enum {
+    HF_FLAG_CAPACITY = 1u,  /* an output store was suppressed: buffer too small */
+    HF_FLAG_DECODE = 2u,    /* window below the smallest key */
+    HF_FLAG_TIMEOUT = 4u    /* a bounded inter-workgroup wait expired */
+};
+
+/* Granularity constants of the side metadata (the "gap array"). */
+enum { HF_SEG_CHUNKS = 256 }; /* chunks per segment */
+
+/* ------------------------------------------------------------------ context */
+
+HF_API int hf_version(void);
+HF_API const char *hf_strerror(int status);
+
+/* Creates a context on HIP device `device` using the null stream. */
+HF_API int hf_ctx_create(int device, hf_ctx **ctx);
+HF_API int hf_ctx_destroy(hf_ctx *ctx);
+/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+HF_API int hf_ctx_set_stream(hf_ctx *ctx, void *stream);
+HF_API int hf_ctx_synchronize(hf_ctx *ctx);
+HF_API const char *hf_last_error(const hf_ctx *ctx);
+/* Tuning knobs for experiments: name in {"enc_mode" (0 = three kernels,
+ * 1 = single pass with chained scan), "hist_grid", "timeout_ms"}. */
+HF_API int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value);
+
+/* -------------------------------------------------------- L0: src/stats.rs */
+
+/* generate_histogram (src/stats.rs:13-28) and the counting loop of
+ * Huffman::from_slice (src/huffman/mod.rs:59-65): 256-bin byte counts of
+ * d_in[0..n).  d_hist is 256 x uint64_t in device memory (overwritten). */
+HF_API int hf_histogram_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d_hist);
+/* Same, then copies the counts to host memory. */
+HF_API int hf_histogram(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t hist[256]);
+
+/* ------------------------------------- L1: src/huffman/mod.rs (host side) */
+
+/* calculate_codeword_length_inplace (src/huffman/mod.rs:71-125): weights in
+ * non-increasing order are replaced by code lengths. */
+HF_API int hf_codeword_lengths_inplace(uint64_t *weights, uint64_t n);
+/* sort_by_value (src/huffman/mod.rs:127-141): (index, count) pairs with
+ * count > 0 in descending count order; equal counts keep ascending index order.
+ * idx/cnt hold up to 256 entries; *m receives the pair count. */
+HF_API int hf_sort_by_value(const uint64_t *store, uint64_t n, uint64_t *idx, uint64_t *cnt,
+                            uint64_t *m);
+/* calculate_codewords_based_on_length (src/huffman/mod.rs:155-171). */
+HF_API int hf_codewords_from_lengths(const uint64_t *lengths, uint64_t n, uint64_t *small_codes,
+                                     uint64_t *big_codes);
+/* generate_extended_codewords (src/huffman/mod.rs:181-206) == what
+ * Huffman::from_histogram (src/huffman/mod.rs:48-51) stores. */
+HF_API int hf_build_codebook(const uint64_t *hist, uint64_t n, uint64_t codes[256],
+                             uint64_t lens[256]);
+/* Model::sentinel (src/huffman/mod.rs:20-26). */
+HF_API uint64_t hf_model_sentinel(const uint64_t lens[256]);
+/* Model::to_btreemap (src/huffman/mod.rs:27-38) flattened: entries sorted by
+ * key = code << (sentinel - len); *m receives the entry count (<= 256). */
+HF_API int hf_model_to_table(const uint64_t codes[256], const uint64_t lens[256],
+                             uint64_t keys[256], uint8_t syms[256], uint8_t klens[256],
+                             uint64_t *m);
+/* calculate_length (src/huffman/encode.rs:140-149). */
+HF_API uint64_t hf_calculate_length(uint64_t val);
+
+/* Huffman::new (src/huffman/mod.rs:45-47): validates the codebook and stages
+ * it on the device (flat symbol -> (code,len) table for encoding, multi-level
+ * lookup table + sorted keys for decoding). */
+HF_API int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[256],
+                           hf_model **model);
+/* Decode-only model from a key table, as Decoder::from_header builds it from
+ * Header.btree (src/huffman/decode/mod.rs:48-66).  keys must be ascending. */
+HF_API int hf_model_from_table(hf_ctx *ctx, const uint64_t *keys, const uint8_t *syms,
+                               const uint8_t *klens, uint64_t m, uint64_t sentinel,
+                               hf_model **model);
+HF_API int hf_model_destroy(hf_model *model);
+
+/* -------------------------------------- L2: src/huffman/encode.rs (device) */
+
+/* Upper bound, in bytes, of the stream hf_encode can produce for n symbols
+ * with this model and lead_bits leading pad bits. */
+HF_API uint64_t hf_encode_bound(const hf_model *model, uint64_t n, uint32_t lead_bits);
+/* Sizes of the side metadata for n symbols: n_chunks = ceil(n / chunk_syms)
+ * entries of chunk_bits, n_segs = ceil(n_chunks / HF_SEG_CHUNKS) entries of
+ * seg_off.  chunk_syms must be 64, 128 or 256 (a decoding workgroup keeps the
+ * output of 256 chunks in LDS). */
+HF_API int hf_gap_layout(uint64_t n, uint32_t chunk_syms, uint64_t *n_chunks, uint64_t *n_segs);
+
+/* Encoder::write over the whole slice followed by Encoder::flush
+ * (src/huffman/encode.rs:91-136): the codes of d_in[0..n) concatenated MSB
+ * first and zero-padded to a whole byte, written to d_out.
+ *   lead_bits   0..7: that many zero bits precede the first code (lets a shard
+ *               be placed at a global bit offset; 0 for a whole stream).
+ *   d_out       4-byte aligned, out_cap bytes.
+ *   d_chunk_bits, d_seg_off   optional (both or neither): the gap array.
+ *               chunk_bits[c] = bit length of chunk c (chunk_syms symbols);
+ *               seg_off[s]    = bit offset (lead_bits included) of the first
+ *               symbol of chunk s * HF_SEG_CHUNKS.
+ *   d_result    HF_RES_WORDS x uint64_t: total bits (lead_bits excluded) and flags.
+ * The stream occupies ceil((lead_bits + total_bits) / 8) bytes. */
+HF_API int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
+                           uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap,
+                           uint32_t chunk_syms, uint16_t *d_chunk_bits, uint64_t *d_seg_off,
+                           uint64_t *d_result);
+/* Synchronous form; *total_bits receives the bit count (lead_bits excluded). */
+HF_API int hf_encode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
+                     uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,
+                     uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint64_t *total_bits);
+
+/* Return value and counters of one Encoder::write call
+ * (src/huffman/encode.rs:91-116).  That value is not the number of input bytes
+ * consumed but `bytes emitted during the call + 8 - trailing_zeros(buffer)/8`,
+ * which depends on the reference's byte-wise `put` / 5-byte `cleanup` schedule
+ * (:57-83).  One device lane replays that schedule over d_in[0..n).
+ *   state  in/out {buffer, remaining_bits, writeout}; a fresh encoder is
+ *          {0, 64, 0} (src/huffman/encode.rs:39-49).
+ *   ret    the value Encoder::write returns.
+ * Sequential by nature: limited to HF_WRITE_VALUE_MAX symbols per call. */
+#define HF_WRITE_VALUE_MAX (1ull << 20)
+HF_API int hf_encoder_write_value(hf_ctx *ctx, const uint8_t *d_in, uint64_t n,
+                                  const uint64_t codes[256], const uint64_t lens[256],
+                                  uint64_t state[3], uint64_t *ret);
+
+/* -------------------------------- L2: src/huffman/decode/mod.rs (device) */
+
+/* decode::read (src/huffman/decode/mod.rs:167-231) / Decoder::read (:70-137)
+ * for chunks [first_chunk, first_chunk + ceil(n_out / chunk_syms)): n_out
+ * symbols are written to d_out.  Lookup is the reference's predecessor search
+ * over the model's keys, so models that are not prefix free decode as they do
+ * in the reference.
+ *   d_in, in_bytes   compressed bytes; bit `bit_base` of the stream is bit 0
+ *                    of d_in[0] (0 for a whole stream); d_in 4-byte aligned.
+ *   d_chunk_bits     entry of chunk first_chunk first.
+ *   d_seg_off        entry of segment first_chunk / HF_SEG_CHUNKS first;
+ *                    first_chunk must be a multiple of HF_SEG_CHUNKS.
+ * Bits past in_bytes read as zero, as the reference's drain loop sees them. */
+HF_API int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in,
+                           uint64_t in_bytes, uint64_t bit_base, uint64_t n_out,
+                           uint32_t chunk_syms, const uint16_t *d_chunk_bits,
+                           const uint64_t *d_seg_off, uint8_t *d_out, uint64_t *d_result);
+HF_API int hf_decode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
+                     uint64_t bit_base, uint64_t n_out, uint32_t chunk_syms,
+                     const uint16_t *d_chunk_bits, const uint64_t *d_seg_off, uint8_t *d_out);
+
+/* The same decode for a stream that carries no gap array (e.g. one written by
+ * the reference): a single sequential walk on the device.  Slow by
+ * construction; meant for small inputs and for rebuilding a gap array. */
+HF_API int hf_decode_serial(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in,
+                            uint64_t in_bytes, uint64_t bit_base, uint64_t n_out,
+                            uint8_t *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HFGPU_H */

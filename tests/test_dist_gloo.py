@@ -1,0 +1,79 @@
+"""world_size-2 and -3 runs of the sharding logic on CPU (gloo): the cross-rank
+bit-offset scan and the byte-wise shard merge, checked against the oracle's
+stream for the whole input."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from huffman_amd import synth
+from huffman_amd.dist import allreduce_histogram, plan_shards
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def shifted_stream(orc, shard, codes, lens, lead):
+    """What hf_encode(lead_bits=lead) produces, from the oracle's stream."""
+    if shard.size == 0:
+        return np.zeros((lead + 7) // 8, dtype=np.uint8), 0
+    stream, _ = orc.encode_slice(shard, codes, lens)
+    nbits = int(np.asarray(lens, dtype=np.uint64)[shard].sum())
+    bits = np.unpackbits(stream)[:nbits]
+    return np.packbits(np.concatenate([np.zeros(lead, dtype=np.uint8), bits])), nbits
+
+
+def worker(rank, world, port, cuts, q):
+    import oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = synth.generate_host("zipf", cuts[-1], seed=77)
+        shard = data[cuts[rank]:cuts[rank + 1]]
+        hist = torch.from_numpy(orc.histogram(shard).astype(np.int64))
+        allreduce_histogram(hist, dist)
+        assert np.array_equal(hist.numpy().astype(np.uint64), orc.histogram(data))
+        codes, lens = orc.generate_extended_codewords(hist.numpy().astype(np.uint64))
+        my_bits = int(lens[shard].sum())
+        plan = plan_shards(my_bits, dist, torch.device("cpu"))
+        local, nbits = shifted_stream(orc, shard, codes, lens, plan.lead_bits)
+        assert nbits == my_bits
+        f, l = plan.byte_range(rank)
+        assert l - f == local.size
+        whole = plan.gather(torch.from_numpy(local), dist, dst=0)
+        if rank == 0:
+            want, _ = orc.encode_slice(data, codes, lens)
+            assert plan.total_bits == int(lens[data].sum())
+            assert np.array_equal(whole.numpy(), want)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover - surfaced through the queue
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cuts", [[0, 5000, 12345], [0, 4099, 4099, 9001], [0, 1, 2, 70000]])
+def test_sharded_streams_concatenate_to_the_reference_stream(cuts):
+    import oracle
+
+    oracle.build()
+    world = len(cuts) - 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, cuts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(world)], results

@@ -1,0 +1,372 @@
+"""GPU parity tests: every result of libhfgpu.so (through its C ABI) against the
+CPU oracle on the same seeded inputs -- bit exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from huffman_amd import synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (there is no CPU fallback)")
+    from huffman_amd import device
+
+    return device
+
+
+def to_gpu(a: np.ndarray):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def numbers_model(orc, words):
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    for w in words:
+        codes[w] = w
+        lens[w] = orc.calculate_length(w)
+    return codes, lens
+
+
+def fib_model(orc, nsym=40):
+    fib = [1, 1]
+    while len(fib) < nsym:
+        fib.append(fib[-1] + fib[-2])
+    hist = np.zeros(256, dtype=np.uint64)
+    hist[:nsym] = fib[::-1]
+    return orc.generate_extended_codewords(hist)
+
+
+SIZES = [1, 2, 63, 64, 65, 255, 4096, 16383, 16384, 16385, 40000, 3 * 16384 + 17, 1 << 20]
+
+
+# ---------------------------------------------------------------- histogram
+
+@pytest.mark.parametrize("kind", ["testfile", "zipf", "uniform", "geometric"])
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 4097, 100003, (1 << 22) + 5])
+def test_histogram_matches_oracle(dev, orc, kind, n):
+    data = synth.generate_host(kind, n, seed=n + 1)
+    got = dev.histogram(to_gpu(data)) if n else dev.histogram(torch.empty(0, dtype=torch.uint8, device="cuda"))
+    assert np.array_equal(got, orc.histogram(data))
+
+
+@pytest.mark.parametrize("offset", [1, 3, 7, 13])
+def test_histogram_unaligned_input(dev, orc, offset):
+    data = synth.generate_host("zipf", 70001, seed=3)
+    t = to_gpu(data)
+    got = dev.histogram(t[offset:])
+    assert np.array_equal(got, orc.histogram(data[offset:]))
+
+
+def test_histogram_kat(dev, kats):
+    k = kats["histogram"]
+    h = dev.histogram(to_gpu(np.array(k["data"], dtype=np.uint8)))
+    for sym, cnt in k["counts"].items():
+        assert h[int(sym)] == cnt
+
+
+# ------------------------------------------------------------------- encode
+
+def check_encode(dev, orc, data, codes, lens, chunk_syms=128, mode=1):
+    model = dev.DeviceModel(codes, lens)
+    model.ctx.set_option("enc_mode", mode)
+    try:
+        enc = dev.encode(to_gpu(data), model, chunk_syms=chunk_syms)
+    finally:
+        model.ctx.set_option("enc_mode", 1)
+    want, _ = orc.encode_slice(data, codes, lens)
+    l = np.asarray(lens, dtype=np.uint64)[data].astype(np.uint64)
+    assert enc.total_bits == int(l.sum())
+    assert enc.nbytes == want.size
+    got = enc.stream().cpu().numpy()
+    assert np.array_equal(got, want)
+    # gap array: bit length of every chunk, start bit of every 256th chunk
+    nch = (data.size + chunk_syms - 1) // chunk_syms
+    pad = np.zeros(nch * chunk_syms, dtype=np.uint64)
+    pad[: data.size] = l
+    per_chunk = pad.reshape(nch, chunk_syms).sum(axis=1)
+    cb = enc.chunk_bits.cpu().numpy().view(np.uint16)[:nch].astype(np.uint64)
+    assert np.array_equal(cb, per_chunk)
+    starts = np.concatenate([[0], np.cumsum(per_chunk)[:-1]])
+    so = enc.seg_off.cpu().numpy().view(np.uint64)[: (nch + 255) // 256]
+    assert np.array_equal(so, starts[::256])
+    return model, enc
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n", SIZES)
+def test_encode_zipf_matches_oracle(dev, orc, n, mode):
+    data = synth.generate_host("zipf", n, seed=n)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    check_encode(dev, orc, data, codes, lens, mode=mode)
+
+
+@pytest.mark.parametrize("kind", ["testfile", "uniform", "geometric"])
+@pytest.mark.parametrize("n", [1, 777, 16384, 200001, 1 << 20])
+def test_encode_other_distributions(dev, orc, kind, n):
+    data = synth.generate_host(kind, n, seed=11 + n)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    check_encode(dev, orc, data, codes, lens)
+
+
+@pytest.mark.parametrize("chunk_syms", [64, 256])
+def test_encode_chunk_sizes(dev, orc, chunk_syms):
+    data = synth.generate_host("zipf", 123457, seed=5)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    check_encode(dev, orc, data, codes, lens, chunk_syms=chunk_syms)
+
+
+def test_product_codebook_equals_oracle_codebook_on_gpu_histogram(dev, orc):
+    data = synth.generate_host("zipf", 1 << 20, seed=99)
+    hist = dev.histogram(to_gpu(data))
+    codes, lens = dev.build_codebook(hist)
+    ocodes, olens = orc.generate_extended_codewords(orc.histogram(data))
+    assert np.array_equal(codes, ocodes) and np.array_equal(lens, olens)
+
+
+def test_encode_numbers_kat(dev, orc, kats):
+    k = kats["encode_numbers"]
+    codes, lens = numbers_model(orc, k["words"])
+    data = np.array(k["words"], dtype=np.uint8)
+    enc = dev.encode(to_gpu(data), dev.DeviceModel(codes, lens))
+    assert list(enc.stream().cpu().numpy()) == k["bytes"]
+    ret, state = dev.encoder_write_value(to_gpu(data), codes, lens, [0, 64, 0])
+    assert ret == k["write_return"]
+
+
+def test_encode_stream_kat(dev, orc, kats):
+    k = kats["encode_stream"]
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    for sym, code in k["codes"].items():
+        codes[int(sym)] = code
+        lens[int(sym)] = orc.calculate_length(code)
+    data = np.array(k["symbols"], dtype=np.uint8)
+    enc = dev.encode(to_gpu(data), dev.DeviceModel(codes, lens))
+    assert list(enc.stream().cpu().numpy()) == k["bytes"]
+    ret, _ = dev.encoder_write_value(to_gpu(data), codes, lens, [0, 64, 0])
+    assert ret == k["write_return"]
+
+
+def test_write_value_follows_reference_schedule_across_calls(dev, orc):
+    data = synth.generate_host("testfile", 20000, seed=2)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    oenc = orc.Encoder(codes, lens)
+    state = [0, 64, 0]
+    t = to_gpu(data)
+    for lo, hi in [(0, 1), (1, 4097), (4097, 8193), (8193, 20000)]:
+        want = oenc.write(data[lo:hi])
+        got, state = dev.encoder_write_value(t[lo:hi], codes, lens, state)
+        assert got == want
+        assert state[2] == oenc.writeout
+
+
+def test_encode_long_codes(dev, orc):
+    codes, lens = fib_model(orc, 40)
+    assert lens.max() > 32
+    rng = np.random.default_rng(8)
+    data = rng.integers(0, 40, size=50000, dtype=np.uint8)
+    model, enc = check_encode(dev, orc, data, codes, lens)
+    out = dev.decode(enc, model)
+    assert np.array_equal(out.cpu().numpy(), data)
+
+
+def test_encode_symbols_without_code_add_no_bits(dev, orc):
+    # absent symbols carry code 0 / length 0 (src/huffman/mod.rs:194-205); if
+    # they occur in the data the reference appends nothing for them
+    hist = np.zeros(256, dtype=np.uint64)
+    hist[:4] = [5, 3, 2, 1]
+    codes, lens = orc.generate_extended_codewords(hist)
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 8, size=70000, dtype=np.uint8)
+    data[16384 - 40: 16384 + 200] = 7   # a run of empty symbols across a tile edge
+    check_encode(dev, orc, data, codes, lens)
+
+
+@pytest.mark.parametrize("lead", [1, 3, 7])
+def test_encode_lead_bits_shift_the_stream(dev, orc, lead):
+    data = synth.generate_host("zipf", 50001, seed=lead)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model, lead_bits=lead)
+    want, _ = orc.encode_slice(data, codes, lens)
+    bits = np.unpackbits(want)[: enc.total_bits]
+    shifted = np.concatenate([np.zeros(lead, dtype=np.uint8), bits])
+    assert np.array_equal(enc.stream().cpu().numpy(), np.packbits(shifted))
+
+
+def test_encode_exact_capacity_and_too_small(dev, orc):
+    from huffman_amd._lib import HfError, HF_ERR_CAPACITY
+
+    data = synth.generate_host("zipf", 100000, seed=1)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    want, _ = orc.encode_slice(data, codes, lens)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model, out_cap=want.size)
+    assert np.array_equal(enc.stream().cpu().numpy(), want)
+    with pytest.raises(HfError) as ei:
+        dev.encode(to_gpu(data), model, out_cap=want.size - 1)
+    assert ei.value.status == HF_ERR_CAPACITY
+
+
+def test_model_validation_errors(dev):
+    from huffman_amd._lib import (HfError, HF_ERR_BAD_CODEBOOK, HF_ERR_CODELEN, HF_ERR_EMPTY,
+                                  HF_ERR_UNSUPPORTED)
+
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    with pytest.raises(HfError) as ei:
+        dev.DeviceModel(codes, lens)
+    assert ei.value.status == HF_ERR_EMPTY
+    lens[1] = 65
+    with pytest.raises(HfError) as ei:
+        dev.DeviceModel(codes, lens)
+    assert ei.value.status == HF_ERR_CODELEN   # InvalidData in the reference
+    lens[1] = 60
+    with pytest.raises(HfError) as ei:
+        dev.DeviceModel(codes, lens)
+    assert ei.value.status == HF_ERR_UNSUPPORTED
+    lens[1] = 3
+    codes[1] = 8
+    with pytest.raises(HfError) as ei:
+        dev.DeviceModel(codes, lens)
+    assert ei.value.status == HF_ERR_BAD_CODEBOOK
+
+
+# ------------------------------------------------------------------- decode
+
+@pytest.mark.parametrize("kind", ["testfile", "zipf", "uniform", "geometric"])
+@pytest.mark.parametrize("n", [1, 63, 129, 32768, 32769, 300007, 1 << 20])
+def test_decode_roundtrip_and_oracle(dev, orc, kind, n):
+    data = synth.generate_host(kind, n, seed=17 + n)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    out = dev.decode(enc, model).cpu().numpy()
+    assert np.array_equal(out, data)
+    stream = enc.stream().cpu().numpy()
+    assert np.array_equal(out, orc.decode_read(stream, codes, lens, n))
+
+
+@pytest.mark.parametrize("chunk_syms", [64, 256])
+def test_decode_chunk_sizes(dev, orc, chunk_syms):
+    data = synth.generate_host("zipf", 200003, seed=4)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model, chunk_syms=chunk_syms)
+    assert np.array_equal(dev.decode(enc, model).cpu().numpy(), data)
+
+
+def test_decode_numbers_not_prefix_free(dev, orc, kats):
+    # predecessor-search semantics: code 1010 is a prefix of 10100101
+    words = kats["decode_numbers"]["words"]
+    codes, lens = numbers_model(orc, words)
+    data = np.array(words, dtype=np.uint8)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    stream = enc.stream().cpu().numpy()
+    want = orc.decode_read(stream, codes, lens, data.size)
+    assert list(want) == words
+    assert np.array_equal(dev.decode(enc, model).cpu().numpy(), want)
+    assert np.array_equal(dev.decode_serial(enc.data, enc.nbytes, model, data.size).cpu().numpy(),
+                          want)
+
+
+def test_decode_not_prefix_free_long_input_fails_like_the_reference(dev, orc, kats):
+    # repeated 50 times the same model loses sync and meets a window below its
+    # smallest key: the reference panics there, the library reports HF_ERR_DECODE
+    from huffman_amd._lib import HfError, HF_ERR_DECODE
+
+    words = kats["decode_numbers"]["words"]
+    codes, lens = numbers_model(orc, words)
+    data = np.array(words * 50, dtype=np.uint8)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    with pytest.raises(ValueError):
+        orc.decode_read(enc.stream().cpu().numpy(), codes, lens, data.size)
+    with pytest.raises(HfError) as ei:
+        dev.decode_serial(enc.data, enc.nbytes, model, data.size)
+    assert ei.value.status == HF_ERR_DECODE
+
+
+def test_decode_histogram_encoded_kat(dev, orc, kats):
+    k = kats["decode_numbers_histogram_encoded"]
+    hist = np.zeros(256, dtype=np.uint64)
+    hist[: len(k["histogram"])] = k["histogram"]
+    codes, lens = dev.build_codebook(hist)
+    data = np.array(k["origin"], dtype=np.uint8)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    assert list(dev.decode(enc, model).cpu().numpy()) == k["origin"]
+    assert list(dev.decode_serial(enc.data, enc.nbytes, model, data.size).cpu().numpy()) == k["origin"]
+
+
+def test_vault_sentences_roundtrip(dev, orc, kats):
+    for sentence in kats["vault_roundtrips"]["sentences"]:
+        data = np.frombuffer(sentence.encode(), dtype=np.uint8)
+        t = to_gpu(data)
+        codes, lens = dev.build_codebook(dev.histogram(t))
+        model = dev.DeviceModel(codes, lens)
+        enc = dev.encode(t, model)
+        want, _ = orc.encode_slice(data, codes, lens)
+        assert np.array_equal(enc.stream().cpu().numpy(), want)
+        assert dev.decode(enc, model).cpu().numpy().tobytes() == sentence.encode()
+
+
+def test_decode_from_header_table(dev, orc):
+    data = synth.generate_host("zipf", 70000, seed=21)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    enc = dev.encode(to_gpu(data), dev.DeviceModel(codes, lens))
+    keys, syms, kl = orc.to_btreemap(codes, lens)
+    dmodel = dev.DeviceModel(table=(keys, syms, kl, orc.sentinel(lens)))
+    assert np.array_equal(dev.decode(enc, dmodel).cpu().numpy(), data)
+
+
+def test_decode_window_below_smallest_key_is_an_error(dev, orc):
+    from huffman_amd._lib import HfError, HF_ERR_DECODE
+
+    # a model without key 0: windows of zero bits have no predecessor
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    codes[1], lens[1] = 1, 1
+    codes[2], lens[2] = 1, 2
+    model = dev.DeviceModel(codes, lens)
+    data = np.array([1, 2, 1, 1], dtype=np.uint8)
+    enc = dev.encode(to_gpu(data), model)
+    with pytest.raises(ValueError):
+        orc.decode_read(enc.stream().cpu().numpy(), codes, lens, 8)
+    enc.n = 8  # ask for more symbols than the stream holds: the zero padding is hit
+    with pytest.raises(HfError) as ei:
+        dev.decode(enc, model)
+    assert ei.value.status == HF_ERR_DECODE
+
+
+# ------------------------------------------------- full-size properties
+
+@pytest.mark.parametrize("kind", ["zipf", "uniform", "geometric"])
+def test_large_roundtrip_properties(dev, kind):
+    n = 1 << 28
+    t = synth.generate_device(kind, n, seed=42)
+    hist = dev.histogram(t)
+    assert int(hist.sum()) == n
+    ref = torch.bincount(t[: 1 << 24].to(torch.int64), minlength=256).cpu().numpy()
+    assert np.array_equal(dev.histogram(t[: 1 << 24]), ref.astype(np.uint64))
+    codes, lens = dev.build_codebook(hist)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(t, model)
+    assert enc.total_bits == int((hist * lens).sum())
+    # both encode schedules must give the same bytes
+    model.ctx.set_option("enc_mode", 0)
+    try:
+        enc0 = dev.encode(t, model)
+    finally:
+        model.ctx.set_option("enc_mode", 1)
+    assert enc0.total_bits == enc.total_bits
+    assert torch.equal(enc0.stream(), enc.stream())
+    assert torch.equal(enc0.chunk_bits, enc.chunk_bits) and torch.equal(enc0.seg_off, enc.seg_off)
+    out = dev.decode(enc, model)
+    assert torch.equal(out, t)
