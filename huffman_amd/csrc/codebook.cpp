@@ -219,6 +219,7 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
     lut->n_sub = 0;
     lut->max_direct_len = 0;
     lut->needs_search = false;
+    lut->has_escape = false;
 
     struct Job {
         size_t base;     // pool offset of the table
@@ -248,8 +249,6 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
                 lut->max_direct_len = std::max<uint32_t>(lut->max_direct_len, klens[plo]);
             } else if (plo != phi && job.depth + job.width + HF_LUT_W2 <= 32 &&
                        lut->n_sub < HF_LUT_MAX_SUB) {
-                // sub-table entries repeat when (i & low bits) differ only in
-                // don't-care bits; that cannot happen here because rem > 0.
                 e = (uint16_t)(0x8000u | lut->n_sub);
                 jobs.push_back({lut->pool.size(), (job.prefix << sig) | part, job.depth + sig,
                                 HF_LUT_W2});
@@ -259,6 +258,7 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
                 e = HF_LUT_SEARCH;
                 lut->needs_search = true;
             }
+            lut->has_escape = lut->has_escape || (e & 0x8000u);
             lut->pool[job.base + i] = e;
         }
     }

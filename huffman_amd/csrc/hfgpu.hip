@@ -140,42 +140,56 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const uint8_t *__res
 
 // ------------------------------------------------------------------- encode
 //
-// A tile is 16384 consecutive symbols; a 256-thread workgroup encodes one
-// tile, each thread a run of 64 consecutive symbols (four 16-byte loads).
-//   1. per-thread bit total from an LDS length table, workgroup scan
-//      -> bit offset of every thread inside the tile (+ the chunk lengths of
-//      the gap array);
+// A tile is 16384 consecutive symbols; a 512-thread workgroup encodes one
+// tile, each thread a run of 32 consecutive symbols (two 16-byte loads).
+//   1. every symbol is looked up ONCE in an LDS table of packed 32-bit
+//      entries (code << 6 | len; four replicas, a lane uses replica lane%4, so
+//      random symbols spread over all banks); the 32 entries stay in
+//      registers.  Their length fields give the thread's bit total; a
+//      workgroup scan turns the totals into bit offsets inside the tile (and
+//      into the chunk lengths of the gap array);
 //   2. start bit of the tile in the stream: either read from a scanned array
 //      (three-kernel mode) or obtained inside the same launch by a chained
 //      scan with decoupled look-back over 8-byte {status,value} descriptors;
 //   3. every thread streams its codes MSB-first through a 64-bit accumulator
-//      and ORs finished 32-bit words into an LDS image of the tile's stream
-//      words (the image is aligned to the stream's 32-bit words);
-//   4. the image is copied out with coalesced, byte-swapped dword stores.
+//      and ORs finished 32-bit words into an LDS image of the tile's part of
+//      the stream (the image is aligned to 16-byte units of the stream); G
+//      neighbouring codes are merged first when G * maxlen <= 32, so the
+//      word-complete test runs once per G symbols;
+//   4. the image is copied out with coalesced, byte-swapped 16-byte stores.
 // Stream words are owned by the tile that contains their first bit, so every
 // output word is written exactly once with a plain store: a tile completes
 // its last word by encoding up to 31 bits of the symbols that follow it and
 // skips the leading word it shares with its predecessor.
+// Codes longer than 25 bits do not fit a packed entry: their entry carries a
+// flag and the length only, and a thread that meets one re-encodes its run
+// from the 64-bit table on a (rare, wave-divergent) side path.
 
-constexpr int ENC_THREADS = 256;
-constexpr int ENC_SPT = 64;
+constexpr int ENC_THREADS = 512;
+constexpr int ENC_WAVES = ENC_THREADS / 64;
+constexpr int ENC_SPT = 32;
 constexpr int ENC_TILE = ENC_THREADS * ENC_SPT; // 16384 symbols
 constexpr int ENC_WINW = 5120;                  // words of stream image per pass (20 KiB)
+constexpr int ENC_REPL = 4;                     // replicas of the packed table in LDS
+constexpr int ENC_BATCH = 4;                    // consecutive tiles per workgroup
+constexpr int ENC_MIN_WAVES = 6;                // waves per SIMD the register budget allows
+constexpr uint32_t ENC_PACKED_MAXLEN = 25;      // longest code a packed entry holds
+constexpr uint32_t ENC_LONG_FLAG = 1u << 31;    // entry of a longer code: flag | len
 
-constexpr unsigned long long DESC_AGG = 1ull << 62;  // tile total published
+constexpr unsigned long long DESC_AGG = 1ull << 62;  // batch total published
 constexpr unsigned long long DESC_INCL = 2ull << 62; // inclusive prefix published
 constexpr unsigned long long DESC_VAL = (1ull << 62) - 1;
 
 struct EncParams {
     const uint8_t *in;
     uint64_t n;
-    const uint64_t *tab;   // 256 x (code << 6 | len)
-    const uint8_t *lentab; // 256 x len
+    const uint64_t *tab;   // 256 x (code << 6 | len), any length up to 57
+    const uint32_t *tab32; // 256 x (code << 6 | len), or ENC_LONG_FLAG | len when len > 25
     uint8_t *out;
     uint64_t out_cap;
     uint32_t lead_bits;
     uint32_t aligned16; // input base is 16-byte aligned
-    uint32_t wide;      // some code is longer than 32 bits
+    uint32_t out_aligned16;
     uint32_t chunk_syms;
     uint16_t *chunk_bits;
     uint64_t *seg_off;
@@ -187,55 +201,75 @@ struct EncParams {
     uint32_t *abort_flag;     // chained mode: set when a wait expired
     uint64_t timeout_ticks;   // in 100 MHz wall-clock ticks
     uint32_t n_tiles;
+    uint32_t first_batch; // batch index of this launch's first workgroup
+    uint32_t debug;       // timing experiments only: bit mask of phases to skip
 };
 
+__device__ __forceinline__ uint32_t enc_sym(const uint32_t raw[ENC_SPT / 4], int k)
+{
+    return (raw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+}
+
+// The thread's 32 symbols as 8 dwords.  FULL = all 32 exist and the input is
+// 16-byte aligned (two 16-byte loads); otherwise byte loads, zeros past the end.
 template <bool FULL>
-__device__ __forceinline__ void enc_load(const uint8_t *__restrict__ in, uint64_t base,
-                                         uint32_t vcnt, uint32_t raw[16])
+__device__ __forceinline__ void enc_load_raw(const EncParams &p, uint64_t base, uint32_t vcnt,
+                                             uint32_t raw[ENC_SPT / 4])
 {
     if (FULL) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint4 v = p[q];
-            raw[4 * q + 0] = v.x;
-            raw[4 * q + 1] = v.y;
-            raw[4 * q + 2] = v.z;
-            raw[4 * q + 3] = v.w;
-        }
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.in + base);
+        const uint4 a = src[0], b = src[1];
+        raw[0] = a.x, raw[1] = a.y, raw[2] = a.z, raw[3] = a.w;
+        raw[4] = b.x, raw[5] = b.y, raw[6] = b.z, raw[7] = b.w;
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < ENC_SPT / 4; ++k)
             raw[k] = 0;
 #pragma unroll
-        for (int k = 0; k < ENC_SPT; ++k)
+        for (int k = 0; k < ENC_SPT; ++k) // static register indices: no scratch
             if ((uint32_t)k < vcnt)
-                raw[k >> 2] |= (uint32_t)in[base + k] << (8 * (k & 3));
+                raw[k >> 2] |= (uint32_t)p.in[base + k] << (8 * (k & 3));
     }
 }
 
-template <bool FULL>
-__device__ __forceinline__ uint32_t enc_sum_lens(const uint32_t raw[16], uint32_t vcnt,
-                                                 const uint8_t *s_len)
+// Bit total of the thread's first vcnt symbols (length fields of the table).
+// Eight lookups are in flight at a time: the fences keep the scheduler from
+// hoisting all 32 (and their registers) to the front.
+__device__ __forceinline__ uint32_t enc_sum_lens(const uint32_t raw[ENC_SPT / 4], uint32_t vcnt,
+                                                 const uint32_t *s_tab)
 {
-    uint32_t sum = 0;
+    const uint32_t *tab = s_tab + (threadIdx.x & (ENC_REPL - 1));
+    const bool full = vcnt == ENC_SPT;
+    uint32_t bits = 0;
 #pragma unroll
-    for (int k = 0; k < ENC_SPT; ++k) {
-        const uint32_t sym = (raw[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        const uint32_t l = s_len[sym];
-        sum += (FULL || (uint32_t)k < vcnt) ? l : 0u;
+    for (int q = 0; q < ENC_SPT / 8; ++q) {
+        uint32_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            e[j] = tab[enc_sym(raw, 8 * q + j) * ENC_REPL];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            bits += (full || (uint32_t)(8 * q + j) < vcnt) ? (e[j] & 63u) : 0u;
+        __builtin_amdgcn_sched_barrier(0);
     }
-    return sum;
+    return bits;
 }
 
 // OR `len` bits of `code` into the stream image at image bit `bitpos`.
 __device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos, uint64_t code,
-                                            uint32_t len, uint32_t wlo, uint32_t whi)
+                                            uint32_t len, uint32_t wlo, uint32_t whi,
+                                            uint32_t clip)
 {
+    if (bitpos + len > clip) { // keep only the bits in front of image bit `clip`
+        const uint32_t keep = clip > bitpos ? clip - bitpos : 0u;
+        code >>= (len - keep);
+        len = keep;
+    }
     while (len > 0) {
         const uint32_t w = bitpos >> 5, o = bitpos & 31u;
         const uint32_t take = min(32u - o, len);
-        const uint32_t part = (uint32_t)(code >> (len - take)) & (take == 32 ? ~0u : ((1u << take) - 1u));
+        const uint32_t part =
+            (uint32_t)(code >> (len - take)) & (take == 32 ? ~0u : ((1u << take) - 1u));
         if (w >= wlo && w < whi)
             __hip_atomic_fetch_or(stg + (w - wlo), part << (32u - o - take), __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -244,82 +278,177 @@ __device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos, uint
     }
 }
 
-template <bool FULL, bool WIDE>
-__device__ __forceinline__ void enc_pack_thread(const uint32_t raw[16], uint32_t vcnt,
-                                                const uint64_t *s_tab, uint32_t *stg,
-                                                uint32_t bitpos, uint32_t nbits, uint32_t wlo,
-                                                uint32_t whi)
-{
-    if (nbits == 0)
-        return;
-    if (((bitpos + nbits - 1) >> 5) < wlo || (bitpos >> 5) >= whi)
-        return;
-    uint32_t w = bitpos >> 5;
-    uint32_t nb = bitpos & 31u; // bits already occupied in word w (by earlier threads)
-    uint64_t acc = 0;           // pending bits, right aligned; bits above nb are stale
-    auto emit = [&](uint32_t val) {
-        if (w >= wlo && w < whi)
-            __hip_atomic_fetch_or(stg + (w - wlo), val, __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+// Bit sink of one thread: codes are appended MSB-first to a 64-bit accumulator
+// and every completed 32-bit word is ORed into the image.  Only image words
+// [wlo, wlo + ENC_WINW) exist in a pass; others are dropped.
+struct EncSink {
+    uint32_t *stg;
+    uint32_t w;   // image word being filled, relative to wlo (wraps below the window)
+    uint32_t nb;  // bits of it that are already spoken for
+    uint64_t acc; // pending bits, right aligned; bits above nb are stale
+    __device__ __forceinline__ EncSink(uint32_t *s, uint32_t bitpos, uint32_t wlo)
+        : stg(s), w((bitpos >> 5) - wlo), nb(bitpos & 31u), acc(0)
+    {
+    }
+    uint32_t dbg = 0;
+    __device__ __forceinline__ void emit(uint32_t val)
+    {
+        if (dbg & 64u) {
+            acc ^= (uint64_t)val << 32; // keep the value alive, no LDS traffic
+        } else if (dbg & 32u) {
+            if (w < (uint32_t)ENC_WINW)
+                stg[w] = val;
+        } else if (w < (uint32_t)ENC_WINW)
+            __hip_atomic_fetch_or(stg + w, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++w;
-    };
-    auto append = [&](uint32_t code, uint32_t len) { // len <= 32, nb < 32
+    }
+    __device__ __forceinline__ void append(uint32_t code, uint32_t len) // len <= 32
+    {
         acc = (acc << len) | code;
         nb += len;
         if (nb >= 32) {
             nb -= 32;
             emit((uint32_t)(acc >> nb));
         }
-    };
-#pragma unroll
-    for (int k = 0; k < ENC_SPT; ++k) {
-        if (!FULL && (uint32_t)k >= vcnt)
-            break;
-        const uint32_t sym = (raw[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        const uint64_t e = s_tab[sym];
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (nb > 0)
+            emit((uint32_t)(acc << (32 - nb)));
+    }
+};
+
+// Generic form: walks the thread's run again through the 64-bit table with a
+// rolled loop.  Used when a code is longer than a packed entry holds and when
+// a tile needs more than one image pass (both rare).
+__device__ inline void enc_pack_thread_rolled(const EncParams &p, uint64_t sym0,
+                                                    uint32_t vcnt, uint32_t *stg, uint32_t bitpos,
+                                                    uint32_t nbits, uint32_t wlo)
+{
+    if (nbits == 0)
+        return;
+    if (((bitpos + nbits - 1) >> 5) < wlo || (bitpos >> 5) >= wlo + ENC_WINW)
+        return;
+    EncSink sink(stg, bitpos, wlo);
+    for (uint32_t k = 0; k < vcnt; ++k) {
+        const uint64_t e = p.tab[p.in[sym0 + k]];
         const uint32_t len = (uint32_t)e & 63u;
-        if (WIDE) {
-            const uint64_t code = e >> 6;
-            if (len > 32) {
-                append((uint32_t)(code >> 32), len - 32);
-                append((uint32_t)code, 32);
-            } else {
-                append((uint32_t)code, len);
-            }
+        const uint64_t code = e >> 6;
+        if (len > 32) {
+            sink.append((uint32_t)(code >> 32), len - 32);
+            sink.append((uint32_t)code, 32);
         } else {
-            append((uint32_t)(e >> 6), len);
+            sink.append((uint32_t)code, len);
         }
     }
-    if (nb > 0)
-        emit((uint32_t)(acc << (32 - nb)));
+    sink.finish();
+}
+
+// Fast form for a tile that fits one image pass.  The packed entries are
+// looked up eight at a time, the next eight while the current eight are
+// appended, so only 16 of them are live; G codes are merged per word-complete
+// test (G * maxlen <= 32).  Codes too long for a packed entry can only occur
+// when G == 1: a group of eight that holds one fetches its codes from the
+// 64-bit table (rare, wave-divergent).
+template <int G>
+__device__ __forceinline__ void enc_pack_thread(const EncParams &p,
+                                                const uint32_t raw[ENC_SPT / 4], uint32_t vcnt,
+                                                const uint32_t *s_tab, uint32_t *stg,
+                                                uint32_t bitpos)
+{
+    const uint32_t *tab = s_tab + (threadIdx.x & (ENC_REPL - 1));
+    const bool full = vcnt == ENC_SPT;
+    EncSink sink(stg, bitpos, 0);
+    sink.dbg = p.debug;
+    uint32_t cur[8], nxt[8];
+    auto fetch = [&](uint32_t e[8], int q) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t v = (p.debug & 128u) ? (enc_sym(raw, 8 * q + j) << 6 | 5u)
+                                                : tab[enc_sym(raw, 8 * q + j) * ENC_REPL];
+            e[j] = (full || (uint32_t)(8 * q + j) < vcnt) ? v : 0u;
+        }
+    };
+    fetch(cur, 0);
+#pragma unroll
+    for (int q = 0; q < ENC_SPT / 8; ++q) {
+        if (q + 1 < ENC_SPT / 8)
+            fetch(nxt, q + 1);
+        bool has_long = false;
+        if (G == 1) {
+            uint32_t any = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                any |= cur[j];
+            has_long = (any & ENC_LONG_FLAG) != 0;
+        }
+        if (G == 1 && __builtin_expect(has_long, 0)) {
+            for (int j = 0; j < 8; ++j) {
+                if (!full && (uint32_t)(8 * q + j) >= vcnt)
+                    break;
+                const uint32_t sym = (raw[2 * q + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
+                const uint64_t e = p.tab[sym];
+                const uint32_t len = (uint32_t)e & 63u;
+                const uint64_t code = e >> 6;
+                if (len > 32) {
+                    sink.append((uint32_t)(code >> 32), len - 32);
+                    sink.append((uint32_t)code, 32);
+                } else {
+                    sink.append((uint32_t)code, len);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k += G) {
+                uint32_t code = cur[k] >> 6, len = cur[k] & 63u;
+#pragma unroll
+                for (int j = 1; j < G; ++j) {
+                    const uint32_t l = cur[k + j] & 63u;
+                    code = (code << l) | (cur[k + j] >> 6);
+                    len += l;
+                }
+                sink.append(code, len);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            cur[j] = nxt[j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    sink.finish();
 }
 
 // Bits of the symbols that follow the tile, up to `need` (< 32) of them, so
-// that the tile's last stream word is complete.  Run by wave 0.  Returns the
-// number of bits that were available (capped once it reaches `need`): fewer
-// than `need` means the input ends inside this tile's last word.
+// that the tile's last stream word is complete.  Run by wave 0; `la_sym` is
+// the symbol at tile_end + lane, loaded together with the tile's own symbols
+// so that no global-memory latency sits between packing and copy-out.
+// Returns the number of bits that were available (capped once it reaches
+// `need`): fewer than `need` means the input ends inside this tile's last word.
 __device__ __forceinline__ uint32_t enc_lookahead(const EncParams &p, uint64_t tile_end,
-                                                  const uint64_t *s_tab, uint32_t *stg,
-                                                  uint32_t endbit, uint32_t need, uint32_t wlo,
-                                                  uint32_t whi)
+                                                  uint32_t la_sym, const uint32_t *s_tab,
+                                                  uint32_t *stg, uint32_t endbit, uint32_t need,
+                                                  uint32_t wlo, uint32_t whi)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t idx = tile_end + lane;
-    const uint64_t e = idx < p.n ? s_tab[p.in[idx]] : 0;
-    const uint32_t len = (uint32_t)e & 63u;
+    uint32_t e32 = idx < p.n ? s_tab[la_sym * ENC_REPL] : 0u;
+    uint64_t code = e32 >> 6;
+    const uint32_t len = e32 & 63u;
+    if (__builtin_expect((e32 & ENC_LONG_FLAG) != 0, 0))
+        code = p.tab[la_sym] >> 6;
     const uint32_t incl = wave_incl_scan(len);
     const uint32_t off = incl - len;
     if (len && off < need)
-        enc_or_bits(stg, endbit + off, e >> 6, len, wlo, whi);
+        enc_or_bits(stg, endbit + off, code, len, wlo, whi, endbit + need);
     uint32_t have = __shfl(incl, 63, 64);
     if (have < need && tile_end + 64 < p.n) {
         // only reachable when the data holds symbols whose code length is 0
         if (lane == 0) {
             for (uint64_t i = tile_end + 64; i < p.n && have < need; ++i) {
-                const uint64_t e2 = s_tab[p.in[i]];
+                const uint64_t e2 = p.tab[p.in[i]];
                 const uint32_t l2 = (uint32_t)e2 & 63u;
                 if (l2)
-                    enc_or_bits(stg, endbit + have, e2 >> 6, l2, wlo, whi);
+                    enc_or_bits(stg, endbit + have, e2 >> 6, l2, wlo, whi, endbit + need);
                 have += l2;
             }
         }
@@ -328,18 +457,18 @@ __device__ __forceinline__ uint32_t enc_lookahead(const EncParams &p, uint64_t t
     return have;
 }
 
-__device__ __forceinline__ void enc_stage_tables(const EncParams &p, uint64_t *s_tab, uint8_t *s_len)
+__device__ __forceinline__ void enc_stage_table(const EncParams &p, uint32_t *s_tab)
 {
-    s_tab[threadIdx.x] = p.tab[threadIdx.x];
-    s_len[threadIdx.x] = p.lentab[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 256 * ENC_REPL; i += ENC_THREADS)
+        s_tab[i] = p.tab32[i / ENC_REPL];
 }
 
 // Three-kernel mode, kernel 1: bit total of every tile.
 __global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
 {
-    __shared__ uint8_t s_len[256];
-    __shared__ uint32_t s_wave[4];
-    s_len[threadIdx.x] = p.lentab[threadIdx.x];
+    __shared__ uint32_t s_tab[256 * ENC_REPL];
+    __shared__ uint32_t s_wave[ENC_WAVES];
+    enc_stage_table(p, s_tab);
     __syncthreads();
     const uint32_t tile = blockIdx.x;
     const uint64_t base = (uint64_t)tile * ENC_TILE;
@@ -347,19 +476,24 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
     const uint32_t nsym = left < ENC_TILE ? (uint32_t)left : ENC_TILE;
     const uint32_t t0 = threadIdx.x * ENC_SPT;
     const uint32_t vcnt = nsym > t0 ? min(nsym - t0, (uint32_t)ENC_SPT) : 0u;
-    uint32_t raw[16];
-    uint32_t sum;
-    if (nsym == ENC_TILE && p.aligned16) {
-        enc_load<true>(p.in, base + t0, vcnt, raw);
-        sum = enc_sum_lens<true>(raw, vcnt, s_len);
-    } else {
-        enc_load<false>(p.in, base + t0, vcnt, raw);
-        sum = enc_sum_lens<false>(raw, vcnt, s_len);
-    }
-    uint32_t total;
-    block_excl_scan256(sum, s_wave, total);
-    if (threadIdx.x == 0)
+    uint32_t raw[ENC_SPT / 4];
+    if (nsym == ENC_TILE && p.aligned16)
+        enc_load_raw<true>(p, base + t0, vcnt, raw);
+    else
+        enc_load_raw<false>(p, base + t0, vcnt, raw);
+    uint32_t sum = enc_sum_lens(raw, vcnt, s_tab);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63u) == 0)
+        s_wave[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int i = 0; i < ENC_WAVES; ++i)
+            total += s_wave[i];
         p.tile_off[tile] = total;
+    }
 }
 
 // Three-kernel mode, kernel 2: in-place exclusive scan of the tile totals by
@@ -384,8 +518,7 @@ __global__ __launch_bounds__(256) void enc_scan_tiles_kernel(uint64_t *tile_off,
         }
         s_part[threadIdx.x] = sum;
         __syncthreads();
-        // Hillis-Steele over 256 partial sums
-        for (uint32_t d = 1; d < 256; d <<= 1) {
+        for (uint32_t d = 1; d < 256; d <<= 1) { // Hillis-Steele over 256 partial sums
             uint64_t t = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
             __syncthreads();
             s_part[threadIdx.x] += t;
@@ -409,7 +542,7 @@ __global__ __launch_bounds__(256) void enc_scan_tiles_kernel(uint64_t *tile_off,
     }
 }
 
-// Decoupled look-back, run by wave 0: exclusive bit prefix of `tile`.
+// Decoupled look-back, run by wave 0: exclusive bit prefix of batch `tile`.
 // Descriptors are single 8-byte words written and read with agent-scope
 // atomics (write-through / L1-bypassing), so the value is its own flag and no
 // other data is handed between workgroups.  Tiles are numbered by a ticket
@@ -429,9 +562,14 @@ __device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, 
             d = idx >= 0 ? __hip_atomic_load(p.desc + idx, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT)
                          : DESC_INCL; // virtual tile -1: inclusive prefix 0
-            if (__all((d >> 62) != 0))
+            // ready once an inclusive prefix is in sight and every descriptor
+            // between it and this batch carries its total
+            const unsigned long long valid = __ballot((d >> 62) != 0);
+            const unsigned long long incl = __ballot((d >> 62) == 2);
+            const unsigned long long below = incl ? ((incl & (0 - incl)) - 1) : ~0ull;
+            if ((valid & below) == below)
                 break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63u) == 0) {
                 const bool expired = wall_clock64() - t_start > p.timeout_ticks;
                 const bool aborted = __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED,
@@ -463,164 +601,273 @@ __device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, 
     return true;
 }
 
-template <bool CHAINED>
-__global__ __launch_bounds__(ENC_THREADS) void enc_pack_kernel(EncParams p)
+// Second half of an image pass: complete the tile's last word from the
+// symbols that follow it (last pass only) and copy the pass's words out with
+// coalesced byte-swapped 16-byte stores, clearing the image on the way.
+__device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *stg, uint32_t *s_ctl,
+                                                const uint32_t *s_tab, uint32_t la_sym,
+                                                uint64_t tile_end, uint64_t E, uint64_t gbase,
+                                                uint64_t g0, uint64_t g1, uint32_t endbit,
+                                                uint32_t need, uint32_t nwords, uint32_t wlo)
 {
-    __shared__ uint64_t s_tab[256];
-    __shared__ uint8_t s_len[256];
-    __shared__ uint32_t s_toff[ENC_THREADS + 1];
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_tile;
-    __shared__ uint64_t s_start;
-    __shared__ uint32_t s_ok;
-    __shared__ uint32_t s_have;
-    __shared__ uint32_t stg[ENC_WINW];
-
-    enc_stage_tables(p, s_tab, s_len);
-    if (CHAINED) {
+    const uint32_t whi = wlo + ENC_WINW;
+    const bool last_pass = nwords - 1 < whi;
+    if (threadIdx.x < 64 && last_pass) {
+        const uint32_t have =
+            need ? enc_lookahead(p, tile_end, la_sym, s_tab, stg, endbit, need, wlo, whi) : 0u;
         if (threadIdx.x == 0)
-            s_tile = atomicAdd(p.ticket, 1u);
+            s_ctl[1] = have;
     }
     __syncthreads();
-    const uint32_t tile = CHAINED ? s_tile : blockIdx.x;
-    if (tile >= p.n_tiles)
-        return;
-
-    const uint64_t base = (uint64_t)tile * ENC_TILE;
-    const uint64_t left = p.n - base;
-    const uint32_t nsym = left < ENC_TILE ? (uint32_t)left : ENC_TILE;
-    const uint64_t tile_end = base + nsym;
-    const uint32_t t0 = threadIdx.x * ENC_SPT;
-    const uint32_t vcnt = nsym > t0 ? min(nsym - t0, (uint32_t)ENC_SPT) : 0u;
-    const bool full = nsym == ENC_TILE && p.aligned16;
-
-    uint32_t raw[16];
-    uint32_t nbits;
-    if (full) {
-        enc_load<true>(p.in, base + t0, vcnt, raw);
-        nbits = enc_sum_lens<true>(raw, vcnt, s_len);
-    } else {
-        enc_load<false>(p.in, base + t0, vcnt, raw);
-        nbits = enc_sum_lens<false>(raw, vcnt, s_len);
-    }
-    uint32_t tile_bits;
-    const uint32_t toff = block_excl_scan256(nbits, s_wave, tile_bits);
-    s_toff[threadIdx.x] = toff;
-    if (threadIdx.x == 0)
-        s_toff[ENC_THREADS] = tile_bits;
-
-    // start bit of the tile in the stream (lead bits included)
-    if (CHAINED) {
-        if (threadIdx.x < 64) {
-            uint64_t excl = 0;
-            bool ok = true;
-            if (tile == 0) {
-                if (threadIdx.x == 0)
-                    __hip_atomic_store(p.desc, DESC_INCL | (unsigned long long)tile_bits,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                if (threadIdx.x == 0)
-                    __hip_atomic_store(p.desc + tile, DESC_AGG | (unsigned long long)tile_bits,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = enc_lookback(p, tile, excl);
-                if (ok && threadIdx.x == 0)
-                    __hip_atomic_store(p.desc + tile,
-                                       DESC_INCL | (unsigned long long)(excl + tile_bits),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (threadIdx.x == 0) {
-                s_start = excl + p.lead_bits;
-                s_ok = ok ? 1u : 0u;
-            }
-        }
-    } else {
-        if (threadIdx.x == 0) {
-            s_start = p.tile_off[tile] + p.lead_bits;
-            s_ok = 1u;
-        }
-    }
-    __syncthreads();
-    if (!s_ok)
-        return; // a wait expired: the host reports HF_ERR_INTERNAL
-    const uint64_t S = s_start;
-    const uint64_t E = S + tile_bits;
-
-    // gap array: bit length of every chunk, start bit of every segment
-    if (p.chunk_bits) {
-        const uint32_t cpt = p.chunk_syms / ENC_SPT;  // threads per chunk
-        const uint32_t cit = ENC_THREADS / cpt;       // chunks per tile
-        if (threadIdx.x < cit) {
-            const uint64_t c = (uint64_t)tile * cit + threadIdx.x;
-            if (c < p.n_chunks) {
-                const uint32_t b0 = s_toff[threadIdx.x * cpt];
-                const uint32_t b1 = s_toff[(threadIdx.x + 1) * cpt];
-                p.chunk_bits[c] = (uint16_t)(b1 - b0);
-                if ((c % HF_SEG_CHUNKS) == 0)
-                    p.seg_off[c / HF_SEG_CHUNKS] = S + b0;
-            }
-        }
-    }
-    if (tile_end == p.n && threadIdx.x == 0)
-        p.result[HF_RES_TOTAL_BITS] = E - p.lead_bits;
-
-    // stream words [g0, g1) belong to this tile
-    const uint64_t gbase = S >> 5;
-    const uint64_t g0 = tile == 0 ? 0 : (S + 31) >> 5;
-    const uint64_t g1 = (E + 31) >> 5;
-    if (g1 <= g0)
-        return;
-    const uint32_t s_lo = (uint32_t)(S & 31u);
-    const uint32_t endbit = s_lo + tile_bits;
-    const uint32_t need = (32u - (endbit & 31u)) & 31u;
-    const uint32_t nwords = (uint32_t)(g1 - gbase);
-    const bool wide = p.wide != 0;
-
-    for (uint32_t wlo = 0; wlo < nwords; wlo += ENC_WINW) {
-        const uint32_t whi = wlo + ENC_WINW;
-        const uint32_t nz = min((uint32_t)ENC_WINW, nwords - wlo);
-        for (uint32_t i = threadIdx.x; i < nz; i += ENC_THREADS)
-            stg[i] = 0;
-        __syncthreads();
-        if (full) {
-            if (wide)
-                enc_pack_thread<true, true>(raw, vcnt, s_tab, stg, s_lo + toff, nbits, wlo, whi);
-            else
-                enc_pack_thread<true, false>(raw, vcnt, s_tab, stg, s_lo + toff, nbits, wlo, whi);
+    // the stream ends inside this tile's last word when fewer than `need`
+    // bits follow the tile: only its leading bytes exist then
+    const uint64_t limit =
+        (need && last_pass && s_ctl[1] < need) ? (E + s_ctl[1] + 7) >> 3 : ~0ull;
+    const uint64_t ga = max(g0, gbase + wlo);
+    const uint64_t gb = min(g1, gbase + whi);
+    // 16-byte units [ua, ub) of the stream intersect [ga, gb); the sweep starts
+    // at the first unit of the image so that the tile's leading bits, which sit
+    // in a word owned by the previous tile, are cleared as well
+    const uint64_t ua = (gbase + wlo) >> 2, ub = (gb + 3) >> 2;
+    for (uint64_t u = ua + threadIdx.x; u < ub; u += ENC_THREADS) {
+        const uint32_t j = (uint32_t)((u << 2) - gbase) - wlo; // image word of the unit
+        const uint4 v = *reinterpret_cast<const uint4 *>(stg + j);
+        // the thread that copies a unit out also clears it: the image is all
+        // zero again when the pass ends, without a separate sweep
+        *reinterpret_cast<uint4 *>(stg + j) = make_uint4(0, 0, 0, 0);
+        const uint32_t vals[4] = {bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)};
+        const uint64_t b = u << 4;
+        if (p.debug & 4u)
+            continue;
+        if ((u << 2) >= ga && (u << 2) + 4 <= gb && b + 16 <= limit && b + 16 <= p.out_cap &&
+            p.out_aligned16) {
+            *reinterpret_cast<uint4 *>(p.out + b) = make_uint4(vals[0], vals[1], vals[2], vals[3]);
         } else {
-            enc_pack_thread<false, true>(raw, vcnt, s_tab, stg, s_lo + toff, nbits, wlo, whi);
-        }
-        if (threadIdx.x < 64 && nwords - 1 >= wlo && nwords - 1 < whi) {
-            const uint32_t have =
-                need ? enc_lookahead(p, tile_end, s_tab, stg, endbit, need, wlo, whi) : 0u;
-            if (threadIdx.x == 0)
-                s_have = have;
-        }
-        __syncthreads();
-        // the stream ends inside this tile's last word when fewer than `need`
-        // bits follow the tile: only its leading bytes exist then
-        const uint64_t limit =
-            (need && nwords - 1 < whi && s_have < need) ? (E + s_have + 7) >> 3 : ~0ull;
-        const uint64_t ga = max(g0, gbase + wlo);
-        const uint64_t gb = min(g1, gbase + whi);
-        for (uint64_t g = ga + threadIdx.x; g < gb; g += ENC_THREADS) {
-            const uint32_t val = bswap32(stg[(uint32_t)(g - gbase) - wlo]);
-            const uint64_t b = g << 2;
-            if (b + 4 <= limit && b + 4 <= p.out_cap) {
-                *reinterpret_cast<uint32_t *>(p.out + b) = val;
-            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (b + i < limit) {
-                        if (b + i < p.out_cap)
-                            p.out[b + i] = (uint8_t)(val >> (8 * i));
-                        else
-                            atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
-                                     (unsigned long long)HF_FLAG_CAPACITY);
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t g = (u << 2) + q;
+                if (g < ga || g >= gb)
+                    continue;
+                const uint64_t bb = g << 2;
+                if (bb + 4 <= limit && bb + 4 <= p.out_cap) {
+                    *reinterpret_cast<uint32_t *>(p.out + bb) = vals[q];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (bb + i < limit) {
+                            if (bb + i < p.out_cap)
+                                p.out[bb + i] = (uint8_t)(vals[q] >> (8 * i));
+                            else
+                                atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
+                                         (unsigned long long)HF_FLAG_CAPACITY);
+                        }
                     }
                 }
             }
         }
-        __syncthreads();
+    }
+    __syncthreads(); // the next pass ORs into units that were just read and cleared
+}
+
+// A workgroup encodes a batch of ENC_BATCH consecutive tiles in two stages.
+// Stage A, all tiles of the batch at once: load the symbols (8 x 16 bytes in
+// flight per thread), sum the code lengths, scan them into per-thread bit
+// offsets (kept in LDS) and, in chained mode, publish the batch's bit total
+// straight away so that later batches never wait for this one's packing.
+// Stage B, tile by tile: pack, complete the last word, copy out.
+// The batch index is a ticket taken at workgroup start (one device-scope
+// atomic per 64 Ki symbols keeps that counter far below its saturation rate);
+// it also orders the look-back: every earlier batch belongs to a workgroup
+// that is already running.
+//
+// FULL = every tile of every batch of this launch has all its symbols and the
+// input is 16-byte aligned; the host launches the (at most one) ragged batch
+// at the end of the input, and unaligned inputs, with FULL = false so that the
+// hot instantiation carries no tail handling.  first_batch offsets the batch
+// index of such a follow-up launch.
+template <int G, bool CHAINED, bool FULL>
+__global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(EncParams p)
+{
+    __shared__ __align__(16) uint32_t stg[ENC_WINW];
+    __shared__ uint32_t s_tab[256 * ENC_REPL];
+    __shared__ uint32_t s_toff[ENC_BATCH][ENC_THREADS + 1];
+    __shared__ uint32_t s_wave[ENC_BATCH][ENC_WAVES];
+    __shared__ uint64_t s_start;
+    __shared__ uint32_t s_ctl[2];
+    __shared__ uint32_t s_batch;
+
+    enc_stage_table(p, s_tab);
+    if (CHAINED) {
+        if (threadIdx.x == 0)
+            s_batch = p.first_batch + atomicAdd(p.ticket, 1u);
+    }
+    for (uint32_t i = threadIdx.x; i < ENC_WINW / 4; i += ENC_THREADS)
+        reinterpret_cast<uint4 *>(stg)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t batch = CHAINED ? s_batch : p.first_batch + blockIdx.x;
+    const uint32_t tile0 = batch * ENC_BATCH;
+    if (tile0 >= p.n_tiles)
+        return;
+    const uint32_t t0 = threadIdx.x * ENC_SPT;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+
+    // ---- stage A
+    uint32_t raw[ENC_BATCH][ENC_SPT / 4];
+    uint32_t vcnt[ENC_BATCH];
+    uint32_t la_sym[ENC_BATCH]; // wave 0: the symbol `lane` places behind each tile
+#pragma unroll
+    for (int t = 0; t < ENC_BATCH; ++t) {
+        const uint64_t base = (uint64_t)(tile0 + t) * ENC_TILE;
+        const uint64_t left = base < p.n ? p.n - base : 0;
+        const uint32_t nsym = left < ENC_TILE ? (uint32_t)left : ENC_TILE;
+        la_sym[t] = 0;
+        if (threadIdx.x < 64 && base + nsym + threadIdx.x < p.n)
+            la_sym[t] = p.in[base + nsym + threadIdx.x];
+        if (FULL)
+            __builtin_assume(nsym == ENC_TILE);
+        vcnt[t] = FULL ? (uint32_t)ENC_SPT : (nsym > t0 ? min(nsym - t0, (uint32_t)ENC_SPT) : 0u);
+        enc_load_raw<FULL>(p, base + t0, vcnt[t], raw[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0); // all global loads of the batch are issued first
+    uint32_t nbits[ENC_BATCH], incl[ENC_BATCH];
+#pragma unroll
+    for (int t = 0; t < ENC_BATCH; ++t) {
+        nbits[t] = (p.debug & 16u) ? 64u + (raw[t][0] & 1u) : enc_sum_lens(raw[t], vcnt[t], s_tab);
+        incl[t] = wave_incl_scan(nbits[t]);
+        if (lane == 63)
+            s_wave[t][wv] = incl[t];
+    }
+    __syncthreads();
+    uint32_t batch_bits = 0;
+#pragma unroll
+    for (int t = 0; t < ENC_BATCH; ++t) {
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < ENC_WAVES; ++i) {
+            const uint32_t x = s_wave[t][i];
+            woff += i < wv ? x : 0u;
+            tot += x;
+        }
+        s_toff[t][threadIdx.x] = woff + incl[t] - nbits[t];
+        if (threadIdx.x == ENC_THREADS - 1)
+            s_toff[t][ENC_THREADS] = tot;
+        batch_bits += tot;
+    }
+
+    // start bit of the batch in the stream (lead bits included)
+    if (CHAINED) {
+        if (threadIdx.x < 64) {
+            uint64_t excl = 0;
+            bool ok = true;
+            if (batch == 0) {
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(p.desc, DESC_INCL | (unsigned long long)batch_bits,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(p.desc + batch, DESC_AGG | (unsigned long long)batch_bits,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(p.debug & 8u))
+                    ok = enc_lookback(p, batch, excl);
+                if (ok && threadIdx.x == 0)
+                    __hip_atomic_store(p.desc + batch,
+                                       DESC_INCL | (unsigned long long)(excl + batch_bits),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (threadIdx.x == 0) {
+                s_start = excl + p.lead_bits;
+                s_ctl[0] = ok ? 1u : 0u;
+            }
+        }
+    } else {
+        if (threadIdx.x == 0) {
+            s_start = p.tile_off[tile0] + p.lead_bits;
+            s_ctl[0] = 1u;
+        }
+    }
+    __syncthreads();
+    if (!s_ctl[0])
+        return; // a wait expired: the host reports HF_ERR_INTERNAL
+    uint64_t S = s_start;
+    if (p.debug & 1u)
+        return;
+
+    // ---- stage B: a rolled loop (one copy of the code); the tile's symbols are
+    // picked out of the batch's registers with selects on the loop counter
+#pragma unroll 1
+    for (uint32_t t = 0; t < ENC_BATCH; ++t) {
+        const uint32_t tile = tile0 + t;
+        if (tile >= p.n_tiles)
+            break;
+        // the table is read again here on purpose: without this fence the
+        // compiler keeps all of stage A's lookups alive (in scratch) instead
+        asm volatile("" ::: "memory");
+        uint32_t rc[ENC_SPT / 4];
+#pragma unroll
+        for (int j = 0; j < ENC_SPT / 4; ++j) {
+            uint32_t v = raw[ENC_BATCH - 1][j];
+#pragma unroll
+            for (int u = ENC_BATCH - 2; u >= 0; --u)
+                v = t == (uint32_t)u ? raw[u][j] : v;
+            rc[j] = v;
+        }
+        uint32_t vc = vcnt[ENC_BATCH - 1], la = la_sym[ENC_BATCH - 1];
+#pragma unroll
+        for (int u = ENC_BATCH - 2; u >= 0; --u) {
+            vc = t == (uint32_t)u ? vcnt[u] : vc;
+            la = t == (uint32_t)u ? la_sym[u] : la;
+        }
+        const uint64_t base = (uint64_t)tile * ENC_TILE;
+        const uint64_t left = p.n - base;
+        const uint64_t tile_end = base + (left < ENC_TILE ? left : (uint64_t)ENC_TILE);
+        const uint32_t tile_bits = s_toff[t][ENC_THREADS];
+        const uint32_t toff = s_toff[t][threadIdx.x];
+        const uint32_t my_bits = s_toff[t][threadIdx.x + 1] - toff;
+        const uint64_t E = S + tile_bits;
+
+        // gap array: bit length of every chunk, start bit of every segment
+        if (p.chunk_bits) {
+            const uint32_t cpt = p.chunk_syms / ENC_SPT; // threads per chunk
+            const uint32_t cit = ENC_THREADS / cpt;      // chunks per tile
+            if (threadIdx.x < cit) {
+                const uint64_t c = (uint64_t)tile * cit + threadIdx.x;
+                if (c < p.n_chunks) {
+                    const uint32_t b0 = s_toff[t][threadIdx.x * cpt];
+                    const uint32_t b1 = s_toff[t][(threadIdx.x + 1) * cpt];
+                    p.chunk_bits[c] = (uint16_t)(b1 - b0);
+                    if ((c % HF_SEG_CHUNKS) == 0)
+                        p.seg_off[c / HF_SEG_CHUNKS] = S + b0;
+                }
+            }
+        }
+        if (tile_end == p.n && threadIdx.x == 0)
+            p.result[HF_RES_TOTAL_BITS] = E - p.lead_bits;
+
+        // stream words [g0, g1) belong to this tile; the image starts at the
+        // 16-byte unit of the stream that holds bit S
+        const uint64_t gbase = (S >> 7) << 2;
+        const uint64_t g0 = tile == 0 ? 0 : (S + 31) >> 5;
+        const uint64_t g1 = (E + 31) >> 5;
+        if (g1 > g0) {
+            const uint32_t s_lo = (uint32_t)(S - (gbase << 5)); // 0..127
+            const uint32_t endbit = s_lo + tile_bits;
+            const uint32_t need = (32u - (endbit & 31u)) & 31u;
+            const uint32_t nwords = (uint32_t)(g1 - gbase);
+            if (nwords <= ENC_WINW) {
+                // common case, straight-line: the whole tile fits one image pass
+                if (my_bits && !(p.debug & 2u))
+                    enc_pack_thread<G>(p, rc, vc, s_tab, stg, s_lo + toff);
+                enc_finish_pass(p, stg, s_ctl, s_tab, la, tile_end, E, gbase, g0, g1, endbit, need,
+                                nwords, 0);
+            } else {
+                for (uint32_t wlo = 0; wlo < nwords; wlo += ENC_WINW) {
+                    enc_pack_thread_rolled(p, base + t0, vc, stg, s_lo + toff, my_bits, wlo);
+                    enc_finish_pass(p, stg, s_ctl, s_tab, la, tile_end, E, gbase, g0, g1, endbit,
+                                    need, nwords, wlo);
+                }
+            }
+        }
+        S = E;
     }
 }
 
@@ -629,10 +876,11 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_pack_kernel(EncParams p)
 // One workgroup decodes one segment = 256 chunks; lane l decodes chunk l
 // (chunk_syms symbols) sequentially.  The chunk start bits come from the gap
 // array: the segment's absolute start plus a workgroup scan of the 16-bit
-// chunk lengths.  The segment's compressed words are staged once, coalesced
-// and byte-swapped, into LDS, and the decoded bytes are collected in a padded
-// LDS image and written out with coalesced 16-byte stores, so global memory
-// only sees whole-line traffic although every lane walks its own bit stream.
+// chunk lengths.  The segment's compressed bytes are staged once, with
+// coalesced 16-byte loads, byte-swapped into an LDS image of big-endian
+// words, and the decoded bytes are collected in a padded LDS image and
+// written out with coalesced 16-byte stores, so global memory only sees
+// whole-line traffic although every lane walks its own bit stream.
 // Symbols are resolved through the LDS-resident multi-level table; the rare
 // slots that the table cannot resolve fall back to a predecessor search over
 // the sorted keys with the full sentinel-wide window.
@@ -659,6 +907,7 @@ struct DecParams {
     const uint8_t *klens;
     uint32_t m;
     uint32_t istg_words;
+    uint32_t in_aligned16;
     uint32_t out_aligned16;
 };
 
@@ -713,78 +962,97 @@ __device__ __forceinline__ uint64_t dec_peek64(const Src &src, uint32_t pos)
     return o ? (hi << o) | ((uint64_t)src(w + 2) >> (32 - o)) : hi;
 }
 
+// MSB-first bit reader over 32-bit words.  The word after the ones already
+// merged into `buf` is kept in a register (`nxt`), so a refill never waits for
+// memory: it merges the register and issues the load of the following word.
 template <typename Src>
 struct BitReader {
     const Src &src;
-    uint64_t buf;  // unread bits, left aligned, zeros below
-    int32_t bits;  // number of valid bits in buf
-    uint32_t wp;   // next word to fetch
+    uint64_t buf; // unread bits, left aligned, zeros below
+    int32_t bits; // number of valid bits in buf
+    uint32_t wp;  // index of the word after nxt
+    uint32_t nxt; // prefetched word wp - 1
     __device__ __forceinline__ BitReader(const Src &s, uint32_t pos) : src(s) { seek(pos); }
     __device__ __forceinline__ void seek(uint32_t pos)
     {
         const uint32_t w = pos >> 5, o = pos & 31u;
         buf = (((uint64_t)src(w) << 32) | src(w + 1)) << o;
         bits = 64 - (int32_t)o;
-        wp = w + 2;
+        nxt = src(w + 2);
+        wp = w + 3;
     }
-    __device__ __forceinline__ uint32_t pos() const { return wp * 32u - (uint32_t)bits; }
+    __device__ __forceinline__ uint32_t pos() const { return (wp - 1) * 32u - (uint32_t)bits; }
     __device__ __forceinline__ void refill()
     {
         if (bits <= 32) {
-            buf |= (uint64_t)src(wp) << (32 - bits);
+            buf |= (uint64_t)nxt << (32 - bits);
             bits += 32;
+            nxt = src(wp);
             ++wp;
         }
     }
 };
 
-// One symbol.  Needs >= 32 valid bits (or >= sentinel bits when the model's
-// sentinel is <= 16) in the reader.
+// Resolves a table entry with the escape bit set: walks the sub-tables, then
+// falls back to the predecessor search.  Consumes the symbol's bits itself.
 template <typename Src>
-__device__ __forceinline__ uint32_t dec_symbol(BitReader<Src> &br, const uint16_t *s_lut,
-                                               const DecParams &p, bool &bad)
+__device__ inline uint32_t dec_escape(BitReader<Src> &br, uint32_t e, const uint16_t *s_lut,
+                                            const DecParams &p, bool &bad)
 {
     const uint32_t hi = (uint32_t)(br.buf >> 32);
-    uint32_t e = s_lut[hi >> (32 - p.w1)];
-    if (__builtin_expect(e & 0x8000u, 0)) {
-        uint32_t used = p.w1;
-        while ((e & 0x8000u) && e < HF_LUT_INVALID) {
-            const uint32_t idx = (hi << used) >> (32 - HF_LUT_W2);
-            e = s_lut[(1u << p.w1) + ((e & 0x7fffu) << HF_LUT_W2) + idx];
-            used += HF_LUT_W2;
-        }
-        if (e >= HF_LUT_INVALID) {
-            uint32_t sym = 0, len = 0;
-            if (e == HF_LUT_SEARCH) {
-                const uint32_t pos = br.pos();
-                const uint64_t window = dec_peek64(br.src, pos) >> (64 - p.sentinel);
-                const int k = dec_predecessor(p.keys, p.m, window);
-                if (k >= 0) {
-                    sym = p.ksyms[k];
-                    len = p.klens[k];
-                } else {
-                    bad = true;
-                }
-                br.seek(pos + len);
-                br.refill();
-                return sym;
-            }
-            bad = true;
-            return 0;
-        }
+    uint32_t used = p.w1;
+    while ((e & 0x8000u) && e < HF_LUT_INVALID) {
+        const uint32_t idx = (hi << used) >> (32 - HF_LUT_W2);
+        e = s_lut[(1u << p.w1) + ((e & 0x7fffu) << HF_LUT_W2) + idx];
+        used += HF_LUT_W2;
     }
+    if (e < HF_LUT_INVALID) {
+        const uint32_t len = e >> 8;
+        br.buf <<= len;
+        br.bits -= (int32_t)len;
+        return e & 0xffu;
+    }
+    if (e == HF_LUT_SEARCH) {
+        const uint32_t pos = br.pos();
+        const uint64_t window = dec_peek64(br.src, pos) >> (64 - p.sentinel);
+        const int k = dec_predecessor(p.keys, p.m, window);
+        uint32_t sym = 0, len = 0;
+        if (k >= 0) {
+            sym = p.ksyms[k];
+            len = p.klens[k];
+        } else {
+            bad = true;
+        }
+        br.seek(pos + len);
+        br.refill();
+        return sym;
+    }
+    bad = true; // window below the smallest key
+    return 0;
+}
+
+// One symbol.  Needs >= 32 valid bits (or >= sentinel bits when the model's
+// sentinel is <= 16) in the reader.  ESC = the table contains escape entries.
+template <typename Src, bool ESC>
+__device__ __forceinline__ uint32_t dec_symbol(BitReader<Src> &br, const uint16_t *s_lut,
+                                               uint32_t shift, const DecParams &p, bool &bad)
+{
+    const uint32_t e = s_lut[(uint32_t)(br.buf >> 32) >> shift];
+    if (ESC && __builtin_expect(e & 0x8000u, 0))
+        return dec_escape(br, e, s_lut, p, bad);
     const uint32_t len = e >> 8;
     br.buf <<= len;
     br.bits -= (int32_t)len;
     return e & 0xffu;
 }
 
-template <typename Src, int SPR>
+template <typename Src, int SPR, bool ESC>
 __device__ __forceinline__ void dec_lane(const Src &src, uint32_t startbit, uint32_t cnt,
                                          const uint16_t *s_lut, const DecParams &p,
                                          uint32_t *orow, bool &bad)
 {
     BitReader<Src> br(src, startbit);
+    const uint32_t shift = 32 - p.w1;
     uint32_t i = 0;
     for (; i + 4 <= cnt; i += 4) {
         uint32_t pack = 0;
@@ -792,7 +1060,7 @@ __device__ __forceinline__ void dec_lane(const Src &src, uint32_t startbit, uint
         for (int k = 0; k < 4; ++k) {
             if ((k % SPR) == 0)
                 br.refill();
-            pack |= dec_symbol(br, s_lut, p, bad) << (8 * k);
+            pack |= dec_symbol<Src, ESC>(br, s_lut, shift, p, bad) << (8 * k);
         }
         orow[i >> 2] = pack;
     }
@@ -800,13 +1068,13 @@ __device__ __forceinline__ void dec_lane(const Src &src, uint32_t startbit, uint
         uint32_t pack = 0;
         for (uint32_t k = 0; i + k < cnt; ++k) {
             br.refill();
-            pack |= dec_symbol(br, s_lut, p, bad) << (8 * k);
+            pack |= dec_symbol<Src, ESC>(br, s_lut, shift, p, bad) << (8 * k);
         }
         orow[i >> 2] = pack;
     }
 }
 
-template <int SPR>
+template <int SPR, bool ESC>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -822,19 +1090,45 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
     const uint64_t c = seg * HF_SEG_CHUNKS + threadIdx.x;
     const bool valid = c < p.n_chunks;
     const uint32_t cb = valid ? p.chunk_bits[c] : 0u;
+    // table: 16-byte loads (the table starts 16-byte aligned in device memory)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.lut);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < lut_bytes / 16; i += DEC_THREADS)
+            dst[i] = src[i];
+    }
     uint32_t total;
     const uint32_t excl = block_excl_scan256(cb, s_wave, total);
     const uint64_t seg_start = p.seg_off[seg] - p.bit_base;
-    const uint64_t wbase = seg_start >> 5;
-    const uint32_t s_lo = (uint32_t)(seg_start & 31u);
-    const uint32_t nw = (s_lo + total + 31u) / 32u + 3u; // +3: readers look up to 64 bits ahead
-    const bool use_lds = nw <= p.istg_words;
-
-    for (uint32_t i = threadIdx.x; i < p.lut_entries; i += DEC_THREADS)
-        s_lut[i] = p.lut[i];
-    if (use_lds)
-        for (uint32_t j = threadIdx.x; j < nw; j += DEC_THREADS)
-            istg[j] = dec_load_word(p.in, p.in_bytes, wbase + j);
+    // the image starts at the 16-byte unit that holds the segment's first bit
+    const uint64_t ubase = seg_start >> 7;
+    const uint32_t s_lo = (uint32_t)(seg_start & 127u);
+    const uint32_t nunits = (s_lo + total + 127u) / 128u + 1u; // +1: readers run ahead
+    const bool use_lds = nunits * 4u <= p.istg_words;
+    if (use_lds) {
+        uint4 *dst = reinterpret_cast<uint4 *>(istg);
+        const uint64_t whole = p.in_bytes >> 4; // units that lie fully inside the buffer
+        if (p.in_aligned16) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.in);
+            for (uint32_t i = threadIdx.x; i < nunits; i += DEC_THREADS) {
+                const uint64_t u = ubase + i;
+                uint4 v;
+                if (u < whole) {
+                    v = src[u];
+                    v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
+                } else {
+                    v.x = dec_load_word(p.in, p.in_bytes, u * 4 + 0);
+                    v.y = dec_load_word(p.in, p.in_bytes, u * 4 + 1);
+                    v.z = dec_load_word(p.in, p.in_bytes, u * 4 + 2);
+                    v.w = dec_load_word(p.in, p.in_bytes, u * 4 + 3);
+                }
+                dst[i] = v;
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < nunits * 4u; i += DEC_THREADS)
+                istg[i] = dec_load_word(p.in, p.in_bytes, ubase * 4 + i);
+        }
+    }
     __syncthreads();
 
     const uint64_t sym0 = c * cs;
@@ -844,10 +1138,10 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
         uint32_t *orow = ostg + threadIdx.x * orow_words;
         if (use_lds) {
             LdsWords src{istg};
-            dec_lane<LdsWords, SPR>(src, s_lo + excl, cnt, s_lut, p, orow, bad);
+            dec_lane<LdsWords, SPR, ESC>(src, s_lo + excl, cnt, s_lut, p, orow, bad);
         } else {
-            GlobalWords src{p.in, p.in_bytes, wbase};
-            dec_lane<GlobalWords, SPR>(src, s_lo + excl, cnt, s_lut, p, orow, bad);
+            GlobalWords src{p.in, p.in_bytes, ubase * 4};
+            dec_lane<GlobalWords, 1, true>(src, s_lo + excl, cnt, s_lut, p, orow, bad);
         }
     }
     if (bad)
@@ -956,13 +1250,14 @@ struct hf_ctx {
     int enc_mode = 1;
     int hist_grid = 0;
     int timeout_ms = 2000;
+    int debug = 0;
 };
 
 struct hf_model {
     hf_ctx *ctx = nullptr;
     void *d_blob = nullptr;
-    uint64_t *d_enc = nullptr; // 256 x (code << 6 | len)
-    uint8_t *d_len = nullptr;
+    uint64_t *d_enc = nullptr;   // 256 x (code << 6 | len)
+    uint32_t *d_enc32 = nullptr; // 256 x (code << 6 | len), or ENC_LONG_FLAG | len
     uint16_t *d_lut = nullptr;
     uint64_t *d_keys = nullptr;
     uint8_t *d_ksyms = nullptr;
@@ -973,6 +1268,7 @@ struct hf_model {
     uint32_t w1 = 0;
     uint32_t maxlen = 0;
     bool has_encode = false;
+    bool lut_escapes = false; // the decode table holds entries with the escape bit
 };
 
 namespace {
@@ -1024,21 +1320,21 @@ int flags_to_status(hf_ctx *ctx, uint64_t flags)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*257 or null*/,
-                 const uint8_t *len_tab, const hf::DecodeLut &lut, const uint64_t *keys,
+int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or null*/,
+                 const uint32_t *enc_tab32, const hf::DecodeLut &lut, const uint64_t *keys,
                  const uint8_t *syms, const uint8_t *klens, uint64_t m)
 {
     const size_t off_enc = 0;
-    const size_t off_len = off_enc + 257 * sizeof(uint64_t);
-    const size_t off_lut = align_up(off_len + 256, 16);
+    const size_t off_enc32 = off_enc + 256 * sizeof(uint64_t);
+    const size_t off_lut = align_up(off_enc32 + 256 * sizeof(uint32_t), 16);
     const size_t off_keys = align_up(off_lut + lut.pool.size() * 2, 16);
     const size_t off_ksyms = off_keys + 256 * sizeof(uint64_t);
     const size_t off_klens = off_ksyms + 256;
     const size_t total = off_klens + 256;
     std::vector<uint8_t> blob(total, 0);
     if (enc_tab) {
-        std::memcpy(blob.data() + off_enc, enc_tab, 257 * sizeof(uint64_t));
-        std::memcpy(blob.data() + off_len, len_tab, 256);
+        std::memcpy(blob.data() + off_enc, enc_tab, 256 * sizeof(uint64_t));
+        std::memcpy(blob.data() + off_enc32, enc_tab32, 256 * sizeof(uint32_t));
     }
     std::memcpy(blob.data() + off_lut, lut.pool.data(), lut.pool.size() * 2);
     std::memcpy(blob.data() + off_keys, keys, m * sizeof(uint64_t));
@@ -1048,7 +1344,7 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*257 or nu
     HF_HIP(ctx, hipMemcpy(mod->d_blob, blob.data(), total, hipMemcpyHostToDevice));
     uint8_t *b = static_cast<uint8_t *>(mod->d_blob);
     mod->d_enc = reinterpret_cast<uint64_t *>(b + off_enc);
-    mod->d_len = b + off_len;
+    mod->d_enc32 = reinterpret_cast<uint32_t *>(b + off_enc32);
     mod->d_lut = reinterpret_cast<uint16_t *>(b + off_lut);
     mod->d_keys = reinterpret_cast<uint64_t *>(b + off_keys);
     mod->d_ksyms = b + off_ksyms;
@@ -1057,6 +1353,7 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*257 or nu
     mod->m = (uint32_t)m;
     mod->sentinel = lut.sentinel;
     mod->w1 = lut.w1;
+    mod->lut_escapes = lut.has_escape;
     return HF_OK;
 }
 
@@ -1156,6 +1453,8 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
         ctx->hist_grid = (int)value;
     else if (!std::strcmp(name, "timeout_ms") && value > 0 && value <= 60000)
         ctx->timeout_ms = (int)value;
+    else if (!std::strcmp(name, "debug") && value >= 0 && value < 256)
+        ctx->debug = (int)value;
     else
         return fail(ctx, HF_ERR_BAD_ARG, "unknown option or value out of range: %s", name);
     return HF_OK;
@@ -1222,13 +1521,13 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
     }
     if (maxlen == 0)
         return fail(ctx, HF_ERR_EMPTY, "model has no symbol with a code");
-    uint64_t enc[257];
-    uint8_t len8[256];
+    uint64_t enc[256];
+    uint32_t enc32[256];
     for (int i = 0; i < 256; ++i) {
         enc[i] = (codes[i] << 6) | lens[i];
-        len8[i] = (uint8_t)lens[i];
+        enc32[i] = lens[i] <= ENC_PACKED_MAXLEN ? (uint32_t)enc[i]
+                                                : (ENC_LONG_FLAG | (uint32_t)lens[i]);
     }
-    enc[256] = 0;
     uint64_t keys[256], m = 0;
     uint8_t syms[256], klens[256];
     int rc = hf::model_table(codes, lens, keys, syms, klens, &m);
@@ -1244,7 +1543,7 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
     mod->ctx = ctx;
     mod->maxlen = (uint32_t)maxlen;
     mod->has_encode = true;
-    rc = upload_model(ctx, mod, enc, len8, lut, keys, syms, klens, m);
+    rc = upload_model(ctx, mod, enc, enc32, lut, keys, syms, klens, m);
     if (rc != HF_OK) {
         delete mod;
         return rc;
@@ -1358,12 +1657,12 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     p.in = d_in;
     p.n = n;
     p.tab = model->d_enc;
-    p.lentab = model->d_len;
+    p.tab32 = model->d_enc32;
     p.out = d_out;
     p.out_cap = out_cap;
     p.lead_bits = lead_bits;
     p.aligned16 = ((uintptr_t)d_in & 15) == 0;
-    p.wide = model->maxlen > 32;
+    p.out_aligned16 = ((uintptr_t)d_out & 15) == 0;
     p.chunk_syms = d_chunk_bits ? chunk_syms : 64;
     p.chunk_bits = d_chunk_bits;
     p.seg_off = d_seg_off;
@@ -1371,26 +1670,46 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     p.result = d_result;
     p.n_tiles = n_tiles;
     p.timeout_ticks = (uint64_t)ctx->timeout_ms * 100000ull;
+    p.debug = (uint32_t)ctx->debug;
 
     const size_t need = ((size_t)n_tiles + 4) * sizeof(uint64_t);
     int rc = ensure_scratch(ctx, need);
     if (rc != HF_OK)
         return rc;
-    if (ctx->enc_mode == 0) {
+    // codes merged per word-complete test: G * maxlen must fit 32 bits
+    const int g = model->maxlen <= 8 ? 4 : (model->maxlen <= 16 ? 2 : 1);
+    const uint32_t n_batches = (n_tiles + ENC_BATCH - 1) / ENC_BATCH;
+    // batches whose tiles are all complete run the lean instantiation; the
+    // ragged last batch (and everything, if the input is unaligned) the general one
+    const uint32_t n_lean = p.aligned16 ? (uint32_t)(n / ((uint64_t)ENC_TILE * ENC_BATCH)) : 0u;
+    const bool chained = ctx->enc_mode != 0;
+    if (!chained) {
         p.tile_off = static_cast<uint64_t *>(ctx->scratch);
         hipLaunchKernelGGL(enc_tile_bits_kernel, dim3(n_tiles), dim3(ENC_THREADS), 0, ctx->stream,
                            p);
         hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(256), 0, ctx->stream, p.tile_off,
                            n_tiles, d_result);
-        hipLaunchKernelGGL(enc_pack_kernel<false>, dim3(n_tiles), dim3(ENC_THREADS), 0,
-                           ctx->stream, p);
     } else {
         HF_HIP(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
         p.desc = static_cast<unsigned long long *>(ctx->scratch);
-        p.ticket = reinterpret_cast<uint32_t *>(p.desc + n_tiles);
-        p.abort_flag = p.ticket + 1;
-        hipLaunchKernelGGL(enc_pack_kernel<true>, dim3(n_tiles), dim3(ENC_THREADS), 0, ctx->stream,
-                           p);
+        p.ticket = reinterpret_cast<uint32_t *>(p.desc + n_batches);
+        p.abort_flag = p.ticket + 2;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool lean = pass == 0;
+        const uint32_t grid = lean ? n_lean : n_batches - n_lean;
+        if (grid == 0)
+            continue;
+        p.first_batch = lean ? 0u : n_lean;
+        void (*kern)(EncParams) = nullptr;
+#define HF_PICK(G)                                                                           \
+    (chained ? (lean ? enc_pack_kernel<G, true, true> : enc_pack_kernel<G, true, false>)     \
+             : (lean ? enc_pack_kernel<G, false, true> : enc_pack_kernel<G, false, false>))
+        kern = g == 4 ? HF_PICK(4) : (g == 2 ? HF_PICK(2) : HF_PICK(1));
+#undef HF_PICK
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), 0, ctx->stream, p);
+        if (chained && lean) // the follow-up launch numbers its own workgroups from zero again
+            p.ticket += 1;
     }
     HF_HIP(ctx, hipGetLastError());
     return HF_OK;
@@ -1471,6 +1790,7 @@ static int fill_dec_params(hf_ctx *ctx, const hf_model *model, const uint8_t *d_
     p->klens = model->d_klens;
     p->m = model->m;
     p->out_aligned16 = ((uintptr_t)d_out & 15) == 0;
+    p->in_aligned16 = ((uintptr_t)d_in & 15) == 0;
     return HF_OK;
 }
 
@@ -1498,14 +1818,20 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     // LDS: table + compressed image (sized for 8 bits per symbol; denser
     // segments read from global memory instead) + padded output image.
     const uint32_t lut_bytes = (model->lut_entries * 2u + 15u) & ~15u;
-    p.istg_words = HF_SEG_CHUNKS * chunk_syms / 4 + 8;
+    p.istg_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
     const uint32_t ostg_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
     const size_t lds = lut_bytes + (size_t)(p.istg_words + ostg_words + 4) * 4;
     if (lds > 160 * 1024 - 64)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: chunk_syms %u needs %zu bytes of LDS",
                     chunk_syms, lds);
+    // symbols decoded per refill test: the reader guarantees 33 valid bits
     const int spr = model->sentinel <= 8 ? 4 : (model->sentinel <= 16 ? 2 : 1);
-    auto kern = spr == 4 ? dec_kernel<4> : (spr == 2 ? dec_kernel<2> : dec_kernel<1>);
+    void (*kern)(DecParams) = nullptr;
+    if (model->lut_escapes)
+        kern = spr == 4 ? dec_kernel<4, true> : (spr == 2 ? dec_kernel<2, true> : dec_kernel<1, true>);
+    else
+        kern = spr == 4 ? dec_kernel<4, false>
+                        : (spr == 2 ? dec_kernel<2, false> : dec_kernel<1, false>);
     HF_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((uint32_t)n_segs), dim3(DEC_THREADS), lds, ctx->stream, p);

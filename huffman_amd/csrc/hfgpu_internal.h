@@ -22,6 +22,7 @@ struct DecodeLut {
     uint32_t n_sub = 0;
     uint32_t max_direct_len = 0;
     bool needs_search = false;
+    bool has_escape = false;    // some entry has the escape bit (sub-table, search, invalid)
     std::vector<uint16_t> pool; // level 1 followed by the sub-tables
 };
 

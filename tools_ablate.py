@@ -1,0 +1,32 @@
+"""Times hf_encode_async with phases skipped (ctx option "debug"); results of
+those runs are wrong on purpose."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from huffman_amd import device as hd, synth
+
+n = 1 << 30
+data = synth.generate_device("zipf", n, seed=2024)
+hist = hd.histogram(data)
+codes, lens = hd.build_codebook(hist)
+model = hd.DeviceModel(codes, lens)
+bufs = hd.EncodeBuffers(model, n, 128)
+ctx = model.ctx
+def run(mode, dbg, reps=5):
+    ctx.set_option("enc_mode", mode)
+    ctx.set_option("debug", dbg)
+    for _ in range(2):
+        hd.encode_async(data, model, bufs)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        hd.encode_async(data, model, bufs)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+names = {0: "full", 1: "stageA+lookback only", 2: "no pack", 8: "no lookback", 9: "stageA only (no lookback)",
+         32: "plain store instead of ds_or", 64: "no emit", 128: "no table lookup in pack", 192: "no emit, no lookup"}
+for mode in (1,):
+    for dbg, name in names.items():
+        print(f"mode {mode} debug {dbg:2d} {name:28s} {run(mode, dbg):.3f} ms", flush=True)
+ctx.set_option("debug", 0)

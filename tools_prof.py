@@ -1,0 +1,28 @@
+"""Runs a few iterations of the three kernels for rocprofv3 (no timing logic)."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from huffman_amd import device as hd, synth
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
+mib = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+cs = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+n = mib << 20
+data = synth.generate_device(kind, n, seed=2024)
+hist = hd.histogram(data)
+codes, lens = hd.build_codebook(hist)
+model = hd.DeviceModel(codes, lens)
+bufs = hd.EncodeBuffers(model, n, cs)
+out = torch.empty(n, dtype=torch.uint8, device="cuda")
+dres = torch.zeros(4, dtype=torch.int64, device="cuda")
+d_hist = torch.empty(256, dtype=torch.int64, device="cuda")
+nbytes = (int((hist * lens).sum()) + 7) // 8
+for _ in range(iters):
+    hd.histogram_async(data, d_hist)
+    hd.encode_async(data, model, bufs)
+    hd.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
+torch.cuda.synchronize()
+assert torch.equal(out, data)
+print("ok", kind, mib, cs)
