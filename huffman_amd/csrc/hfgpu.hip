@@ -1169,6 +1169,129 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
     }
 }
 
+// Register-output form of the decode kernel for models whose table has no
+// escape entries (every code fits the first-level index) and 64-symbol chunks.
+// A lane keeps its CS decoded bytes in CS/4 registers (the symbol loop is
+// fully unrolled), so the LDS image of the compressed words can be reused for
+// the output once every lane has finished reading it: a workgroup needs
+// max(input, output) bytes of LDS instead of their sum, which nearly doubles
+// the number of resident workgroups -- and decoding is bound by the latency of
+// its dependent table lookups, i.e. by the number of chunks in flight.
+// Lanes whose chunk is ragged (end of the stream) and segments too dense for
+// the image take a rolled loop that stores bytes straight to global memory.
+template <int CS, int SPR>
+__global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr uint32_t OROW = CS / 4 + 1; // +1: lanes start on different banks
+    const uint32_t lut_bytes = (p.lut_entries * 2u + 15u) & ~15u;
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *img = reinterpret_cast<uint32_t *>(smem + lut_bytes); // input, then output
+    uint32_t *s_wave = img + p.istg_words;
+
+    const uint64_t seg = blockIdx.x;
+    const uint64_t c = seg * HF_SEG_CHUNKS + threadIdx.x;
+    const bool valid = c < p.n_chunks;
+    const uint32_t cb = valid ? p.chunk_bits[c] : 0u;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.lut);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < lut_bytes / 16; i += DEC_THREADS)
+            dst[i] = src[i];
+    }
+    uint32_t total;
+    const uint32_t excl = block_excl_scan256(cb, s_wave, total);
+    const uint64_t seg_start = p.seg_off[seg] - p.bit_base;
+    const uint64_t ubase = seg_start >> 7;
+    const uint32_t s_lo = (uint32_t)(seg_start & 127u);
+    const uint32_t nunits = (s_lo + total + 127u) / 128u + 1u; // +1: readers run ahead
+    const bool use_lds = nunits * 4u <= (uint32_t)(HF_SEG_CHUNKS * CS / 4 + 16) && p.in_aligned16;
+    if (use_lds) {
+        uint4 *dst = reinterpret_cast<uint4 *>(img);
+        const uint64_t whole = p.in_bytes >> 4;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.in);
+        for (uint32_t i = threadIdx.x; i < nunits; i += DEC_THREADS) {
+            const uint64_t u = ubase + i;
+            uint4 v;
+            if (u < whole) {
+                v = src[u];
+                v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
+            } else {
+                v.x = dec_load_word(p.in, p.in_bytes, u * 4 + 0);
+                v.y = dec_load_word(p.in, p.in_bytes, u * 4 + 1);
+                v.z = dec_load_word(p.in, p.in_bytes, u * 4 + 2);
+                v.w = dec_load_word(p.in, p.in_bytes, u * 4 + 3);
+            }
+            dst[i] = v;
+        }
+    }
+    __syncthreads();
+
+    const uint64_t sym0 = c * CS;
+    const uint32_t cnt = valid ? (uint32_t)min((uint64_t)CS, p.n_out - sym0) : 0u;
+    const bool fast = use_lds && cnt == (uint32_t)CS;
+    uint32_t outw[CS / 4];
+    bool bad = false;
+    if (fast) {
+        LdsWords src{img};
+        BitReader<LdsWords> br(src, s_lo + excl);
+        const uint32_t shift = 32 - p.w1;
+#pragma unroll
+        for (int i = 0; i < CS / 4; ++i) {
+            uint32_t pack = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (((4 * i + k) % SPR) == 0)
+                    br.refill();
+                pack |= dec_symbol<LdsWords, false>(br, s_lut, shift, p, bad) << (8 * k);
+            }
+            outw[i] = pack;
+        }
+    } else if (cnt) {
+        // ragged chunk or oversized segment: bytes go straight to global memory
+        GlobalWords src{p.in, p.in_bytes, ubase * 4};
+        BitReader<GlobalWords> br(src, s_lo + excl);
+        const uint32_t shift = 32 - p.w1;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            br.refill();
+            p.out[sym0 + i] = (uint8_t)dec_symbol<GlobalWords, true>(br, s_lut, shift, p, bad);
+        }
+    }
+    if (bad)
+        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
+    __syncthreads(); // every lane is done with the compressed image: reuse it for the output
+    if (fast) {
+        uint32_t *orow = img + threadIdx.x * OROW;
+#pragma unroll
+        for (int i = 0; i < CS / 4; ++i)
+            orow[i] = outw[i];
+    }
+    __syncthreads();
+    if (!use_lds)
+        return;
+    // coalesced copy-out of the whole chunks of the segment
+    const uint64_t obase = seg * HF_SEG_CHUNKS * (uint64_t)CS;
+    const uint64_t oleft = p.n_out - obase;
+    const uint32_t full_chunks = (uint32_t)min(oleft / CS, (uint64_t)HF_SEG_CHUNKS);
+    const uint32_t seg_len = full_chunks * CS;
+    for (uint32_t o = threadIdx.x * 16u; o < seg_len; o += DEC_THREADS * 16u) {
+        const uint32_t ch = o / CS, within = o % CS;
+        const uint32_t *srcw = img + ch * OROW + within / 4;
+        uint4 v;
+        v.x = srcw[0];
+        v.y = srcw[1];
+        v.z = srcw[2];
+        v.w = srcw[3];
+        if (p.out_aligned16) {
+            *reinterpret_cast<uint4 *>(p.out + obase + o) = v;
+        } else {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t i = 0; i < 16u; ++i)
+                p.out[obase + o + i] = (uint8_t)(vv[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
 // Gap-free decode: one lane walks the whole stream with predecessor search.
 __global__ void dec_serial_kernel(DecParams p)
 {
@@ -1453,7 +1576,7 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
         ctx->hist_grid = (int)value;
     else if (!std::strcmp(name, "timeout_ms") && value > 0 && value <= 60000)
         ctx->timeout_ms = (int)value;
-    else if (!std::strcmp(name, "debug") && value >= 0 && value < 256)
+    else if (!std::strcmp(name, "debug") && value >= 0 && value < 512)
         ctx->debug = (int)value;
     else
         return fail(ctx, HF_ERR_BAD_ARG, "unknown option or value out of range: %s", name);
@@ -1818,20 +1941,32 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     // LDS: table + compressed image (sized for 8 bits per symbol; denser
     // segments read from global memory instead) + padded output image.
     const uint32_t lut_bytes = (model->lut_entries * 2u + 15u) & ~15u;
-    p.istg_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
-    const uint32_t ostg_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
-    const size_t lds = lut_bytes + (size_t)(p.istg_words + ostg_words + 4) * 4;
-    if (lds > 160 * 1024 - 64)
-        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: chunk_syms %u needs %zu bytes of LDS",
-                    chunk_syms, lds);
     // symbols decoded per refill test: the reader guarantees 33 valid bits
     const int spr = model->sentinel <= 8 ? 4 : (model->sentinel <= 16 ? 2 : 1);
     void (*kern)(DecParams) = nullptr;
-    if (model->lut_escapes)
-        kern = spr == 4 ? dec_kernel<4, true> : (spr == 2 ? dec_kernel<2, true> : dec_kernel<1, true>);
-    else
-        kern = spr == 4 ? dec_kernel<4, false>
-                        : (spr == 2 ? dec_kernel<2, false> : dec_kernel<1, false>);
+    size_t lds = 0;
+    if (!model->lut_escapes && chunk_syms == 64 && !(ctx->debug & 256)) {
+        // register-output kernel: one LDS image serves as input, then as output
+        const uint32_t in_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
+        const uint32_t out_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
+        p.istg_words = std::max(in_words, out_words);
+        lds = lut_bytes + (size_t)(p.istg_words + 4) * 4;
+        kern = spr == 4 ? dec_kernel_reg<64, 4>
+                        : (spr == 2 ? dec_kernel_reg<64, 2> : dec_kernel_reg<64, 1>);
+    } else {
+        p.istg_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
+        const uint32_t ostg_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
+        lds = lut_bytes + (size_t)(p.istg_words + ostg_words + 4) * 4;
+        if (model->lut_escapes)
+            kern = spr == 4 ? dec_kernel<4, true>
+                            : (spr == 2 ? dec_kernel<2, true> : dec_kernel<1, true>);
+        else
+            kern = spr == 4 ? dec_kernel<4, false>
+                            : (spr == 2 ? dec_kernel<2, false> : dec_kernel<1, false>);
+    }
+    if (lds > 160 * 1024 - 64)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: chunk_syms %u needs %zu bytes of LDS",
+                    chunk_syms, lds);
     HF_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((uint32_t)n_segs), dim3(DEC_THREADS), lds, ctx->stream, p);

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import HfError, lib, u8p, u64p
 
-DEFAULT_CHUNK_SYMS = 128
+DEFAULT_CHUNK_SYMS = 64
 
 
 def _np_u64(a) -> np.ndarray:

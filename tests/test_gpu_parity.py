@@ -71,7 +71,7 @@ def test_histogram_kat(dev, kats):
 
 # ------------------------------------------------------------------- encode
 
-def check_encode(dev, orc, data, codes, lens, chunk_syms=128, mode=1):
+def check_encode(dev, orc, data, codes, lens, chunk_syms=64, mode=1):
     model = dev.DeviceModel(codes, lens)
     model.ctx.set_option("enc_mode", mode)
     try:
@@ -113,7 +113,7 @@ def test_encode_other_distributions(dev, orc, kind, n):
     check_encode(dev, orc, data, codes, lens)
 
 
-@pytest.mark.parametrize("chunk_syms", [64, 256])
+@pytest.mark.parametrize("chunk_syms", [128, 256])
 def test_encode_chunk_sizes(dev, orc, chunk_syms):
     data = synth.generate_host("zipf", 123457, seed=5)
     codes, lens = orc.generate_extended_codewords(orc.histogram(data))
@@ -252,7 +252,7 @@ def test_decode_roundtrip_and_oracle(dev, orc, kind, n):
     assert np.array_equal(out, orc.decode_read(stream, codes, lens, n))
 
 
-@pytest.mark.parametrize("chunk_syms", [64, 256])
+@pytest.mark.parametrize("chunk_syms", [128, 256])
 def test_decode_chunk_sizes(dev, orc, chunk_syms):
     data = synth.generate_host("zipf", 200003, seed=4)
     codes, lens = orc.generate_extended_codewords(orc.histogram(data))
