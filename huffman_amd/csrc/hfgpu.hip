@@ -173,8 +173,8 @@ constexpr int ENC_WINW = 5120;                  // words of stream image per pas
 constexpr int ENC_REPL = 4;                     // replicas of the packed table in LDS
 constexpr int ENC_BATCH = 4;                    // consecutive tiles per workgroup
 constexpr int ENC_MIN_WAVES = 6;                // waves per SIMD the register budget allows
-constexpr uint32_t ENC_PACKED_MAXLEN = 25;      // longest code a packed entry holds
-constexpr uint32_t ENC_LONG_FLAG = 1u << 31;    // entry of a longer code: flag | len
+constexpr uint32_t ENC_PACKED_MAXLEN = 32;      // longest code a split {code, len} entry holds
+constexpr uint32_t ENC_LONG_FLAG = 1u << 31;    // len word of a longer code: flag | len
 
 constexpr unsigned long long DESC_AGG = 1ull << 62;  // batch total published
 constexpr unsigned long long DESC_INCL = 2ull << 62; // inclusive prefix published
@@ -184,7 +184,8 @@ struct EncParams {
     const uint8_t *in;
     uint64_t n;
     const uint64_t *tab;   // 256 x (code << 6 | len), any length up to 57
-    const uint32_t *tab32; // 256 x (code << 6 | len), or ENC_LONG_FLAG | len when len > 25
+    const uint2 *tab2;     // 256 x {code, len}; {0, ENC_LONG_FLAG | len} when len > 32
+    const uint8_t *len8;   // 256 x len
     uint8_t *out;
     uint64_t out_cap;
     uint32_t lead_bits;
@@ -232,24 +233,24 @@ __device__ __forceinline__ void enc_load_raw(const EncParams &p, uint64_t base, 
     }
 }
 
-// Bit total of the thread's first vcnt symbols (length fields of the table).
+// Bit total of the thread's first vcnt symbols from the byte table of code
+// lengths (one extract, one LDS byte read and a third of an add per symbol).
 // Eight lookups are in flight at a time: the fences keep the scheduler from
 // hoisting all 32 (and their registers) to the front.
+template <bool FULL>
 __device__ __forceinline__ uint32_t enc_sum_lens(const uint32_t raw[ENC_SPT / 4], uint32_t vcnt,
-                                                 const uint32_t *s_tab)
+                                                 const uint8_t *s_len)
 {
-    const uint32_t *tab = s_tab + (threadIdx.x & (ENC_REPL - 1));
-    const bool full = vcnt == ENC_SPT;
     uint32_t bits = 0;
 #pragma unroll
     for (int q = 0; q < ENC_SPT / 8; ++q) {
         uint32_t e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            e[j] = tab[enc_sym(raw, 8 * q + j) * ENC_REPL];
+            e[j] = s_len[enc_sym(raw, 8 * q + j)];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            bits += (full || (uint32_t)(8 * q + j) < vcnt) ? (e[j] & 63u) : 0u;
+            bits += (FULL || (uint32_t)(8 * q + j) < vcnt) ? e[j] : 0u;
         __builtin_amdgcn_sched_barrier(0);
     }
     return bits;
@@ -290,15 +291,9 @@ struct EncSink {
         : stg(s), w((bitpos >> 5) - wlo), nb(bitpos & 31u), acc(0)
     {
     }
-    uint32_t dbg = 0;
     __device__ __forceinline__ void emit(uint32_t val)
     {
-        if (dbg & 64u) {
-            acc ^= (uint64_t)val << 32; // keep the value alive, no LDS traffic
-        } else if (dbg & 32u) {
-            if (w < (uint32_t)ENC_WINW)
-                stg[w] = val;
-        } else if (w < (uint32_t)ENC_WINW)
+        if (w < (uint32_t)ENC_WINW)
             __hip_atomic_fetch_or(stg + w, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++w;
     }
@@ -315,6 +310,37 @@ struct EncSink {
     {
         if (nb > 0)
             emit((uint32_t)(acc << (32 - nb)));
+    }
+};
+
+// The same sink without branches, for the single-pass fast path: every append
+// issues one LDS OR.  A lane whose word is complete ORs it into the image; the
+// others OR a don't-care value into a private dump slot behind the image, so
+// the wave never diverges and never waits on a scalar branch.
+struct EncSinkFlat {
+    uint32_t *ptr;  // image word being filled
+    uint32_t *dump; // this lane's dump slot
+    uint32_t nb;
+    uint64_t acc;
+    __device__ __forceinline__ EncSinkFlat(uint32_t *stg, uint32_t *dumps, uint32_t bitpos)
+        : ptr(stg + (bitpos >> 5)), dump(dumps + threadIdx.x), nb(bitpos & 31u), acc(0)
+    {
+    }
+    __device__ __forceinline__ void append(uint32_t code, uint32_t len) // len <= 32
+    {
+        acc = (acc << len) | code;
+        nb += len;
+        const bool full = nb >= 32;
+        nb &= 31u;
+        const uint32_t word = (uint32_t)(acc >> nb);
+        __hip_atomic_fetch_or(full ? ptr : dump, word, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_WORKGROUP);
+        ptr += full ? 1 : 0;
+    }
+    __device__ __forceinline__ void finish()
+    {
+        const uint32_t word = nb ? (uint32_t)(acc << (32 - nb)) : 0u;
+        __hip_atomic_fetch_or(ptr, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
 
@@ -344,49 +370,62 @@ __device__ inline void enc_pack_thread_rolled(const EncParams &p, uint64_t sym0,
     sink.finish();
 }
 
-// Fast form for a tile that fits one image pass.  The packed entries are
-// looked up eight at a time, the next eight while the current eight are
-// appended, so only 16 of them are live; G codes are merged per word-complete
-// test (G * maxlen <= 32).  Codes too long for a packed entry can only occur
-// when G == 1: a group of eight that holds one fetches its codes from the
-// 64-bit table (rare, wave-divergent).
-template <int G>
-__device__ __forceinline__ void enc_pack_thread(const EncParams &p,
-                                                const uint32_t raw[ENC_SPT / 4], uint32_t vcnt,
-                                                const uint32_t *s_tab, uint32_t *stg,
-                                                uint32_t bitpos)
+// Fast form for a tile that fits one image pass.  The {code, len} entries are
+// looked up four at a time (64-bit LDS reads, no field extraction), the next
+// four while the current four are appended, so only eight of them are live;
+// G codes are merged per append (G * maxlen <= 32).  Codes longer than 32 bits
+// can only occur when G == 1: a group of four that holds one fetches its
+// codes from the 64-bit table (rare, wave-divergent).
+// Dword q of tile t's symbols, picked out of the batch's registers by masking
+// (q is a compile-time constant at every use).  Written with AND/OR on
+// purpose: a chain of selects on t is recognised as raw[t][q] and turns the
+// whole array into a scratch-memory object.
+__device__ __forceinline__ uint32_t enc_pick(const uint32_t (&raw)[ENC_BATCH][ENC_SPT / 4],
+                                             uint32_t t, int q)
 {
-    const uint32_t *tab = s_tab + (threadIdx.x & (ENC_REPL - 1));
-    const bool full = vcnt == ENC_SPT;
-    EncSink sink(stg, bitpos, 0);
-    sink.dbg = p.debug;
-    uint32_t cur[8], nxt[8];
-    auto fetch = [&](uint32_t e[8], int q) {
+    uint32_t v = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t v = (p.debug & 128u) ? (enc_sym(raw, 8 * q + j) << 6 | 5u)
-                                                : tab[enc_sym(raw, 8 * q + j) * ENC_REPL];
-            e[j] = (full || (uint32_t)(8 * q + j) < vcnt) ? v : 0u;
+    for (int u = 0; u < ENC_BATCH; ++u)
+        v |= raw[u][q] & (0u - (uint32_t)(t == (uint32_t)u));
+    return v;
+}
+
+template <int G, bool FULL>
+__device__ __forceinline__ void enc_pack_thread(const EncParams &p,
+                                                const uint32_t (&raw)[ENC_BATCH][ENC_SPT / 4],
+                                                uint32_t t, uint32_t vcnt, const uint2 *s_tab2,
+                                                uint32_t *stg, uint32_t *dumps, uint32_t bitpos)
+{
+    constexpr int LG = 4; // lookups per group = the four symbols of one input dword
+    const uint2 *tab = s_tab2 + (threadIdx.x & (ENC_REPL - 1));
+    EncSinkFlat sink(stg, dumps, bitpos);
+    uint2 cur[LG], nxt[LG];
+    auto fetch = [&](uint2 e[LG], int q) {
+        const uint32_t dw = enc_pick(raw, t, q); // the four symbols of this group
+#pragma unroll
+        for (int j = 0; j < LG; ++j) {
+            const uint2 v = tab[((dw >> (8 * j)) & 0xffu) * ENC_REPL];
+            e[j] = (FULL || (uint32_t)(LG * q + j) < vcnt) ? v : make_uint2(0, 0);
         }
     };
     fetch(cur, 0);
 #pragma unroll
-    for (int q = 0; q < ENC_SPT / 8; ++q) {
-        if (q + 1 < ENC_SPT / 8)
+    for (int q = 0; q < ENC_SPT / LG; ++q) {
+        if (q + 1 < ENC_SPT / LG)
             fetch(nxt, q + 1);
         bool has_long = false;
         if (G == 1) {
             uint32_t any = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                any |= cur[j];
+            for (int j = 0; j < LG; ++j)
+                any |= cur[j].y;
             has_long = (any & ENC_LONG_FLAG) != 0;
         }
         if (G == 1 && __builtin_expect(has_long, 0)) {
-            for (int j = 0; j < 8; ++j) {
-                if (!full && (uint32_t)(8 * q + j) >= vcnt)
+            for (int j = 0; j < LG; ++j) {
+                if (!FULL && (uint32_t)(LG * q + j) >= vcnt)
                     break;
-                const uint32_t sym = (raw[2 * q + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
+                const uint32_t sym = (enc_pick(raw, t, q) >> (8 * j)) & 0xffu;
                 const uint64_t e = p.tab[sym];
                 const uint32_t len = (uint32_t)e & 63u;
                 const uint64_t code = e >> 6;
@@ -399,19 +438,18 @@ __device__ __forceinline__ void enc_pack_thread(const EncParams &p,
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; k += G) {
-                uint32_t code = cur[k] >> 6, len = cur[k] & 63u;
+            for (int k = 0; k < LG; k += G) {
+                uint32_t code = cur[k].x, len = cur[k].y;
 #pragma unroll
                 for (int j = 1; j < G; ++j) {
-                    const uint32_t l = cur[k + j] & 63u;
-                    code = (code << l) | (cur[k + j] >> 6);
-                    len += l;
+                    code = (code << cur[k + j].y) | cur[k + j].x;
+                    len += cur[k + j].y;
                 }
                 sink.append(code, len);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < LG; ++j)
             cur[j] = nxt[j];
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -425,16 +463,16 @@ __device__ __forceinline__ void enc_pack_thread(const EncParams &p,
 // Returns the number of bits that were available (capped once it reaches
 // `need`): fewer than `need` means the input ends inside this tile's last word.
 __device__ __forceinline__ uint32_t enc_lookahead(const EncParams &p, uint64_t tile_end,
-                                                  uint32_t la_sym, const uint32_t *s_tab,
+                                                  uint32_t la_sym, const uint2 *s_tab2,
                                                   uint32_t *stg, uint32_t endbit, uint32_t need,
                                                   uint32_t wlo, uint32_t whi)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t idx = tile_end + lane;
-    uint32_t e32 = idx < p.n ? s_tab[la_sym * ENC_REPL] : 0u;
-    uint64_t code = e32 >> 6;
-    const uint32_t len = e32 & 63u;
-    if (__builtin_expect((e32 & ENC_LONG_FLAG) != 0, 0))
+    const uint2 e2x = idx < p.n ? s_tab2[la_sym * ENC_REPL] : make_uint2(0, 0);
+    uint64_t code = e2x.x;
+    const uint32_t len = e2x.y & 63u;
+    if (__builtin_expect((e2x.y & ENC_LONG_FLAG) != 0, 0))
         code = p.tab[la_sym] >> 6;
     const uint32_t incl = wave_incl_scan(len);
     const uint32_t off = incl - len;
@@ -457,18 +495,23 @@ __device__ __forceinline__ uint32_t enc_lookahead(const EncParams &p, uint64_t t
     return have;
 }
 
-__device__ __forceinline__ void enc_stage_table(const EncParams &p, uint32_t *s_tab)
+__device__ __forceinline__ void enc_stage_table(const EncParams &p, uint2 *s_tab2, uint8_t *s_len)
 {
     for (uint32_t i = threadIdx.x; i < 256 * ENC_REPL; i += ENC_THREADS)
-        s_tab[i] = p.tab32[i / ENC_REPL];
+        s_tab2[i] = p.tab2[i / ENC_REPL];
+    if (threadIdx.x < 64)
+        reinterpret_cast<uint32_t *>(s_len)[threadIdx.x] =
+            reinterpret_cast<const uint32_t *>(p.len8)[threadIdx.x];
 }
 
 // Three-kernel mode, kernel 1: bit total of every tile.
 __global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
 {
-    __shared__ uint32_t s_tab[256 * ENC_REPL];
+    __shared__ __align__(16) uint8_t s_len[256];
     __shared__ uint32_t s_wave[ENC_WAVES];
-    enc_stage_table(p, s_tab);
+    if (threadIdx.x < 64)
+        reinterpret_cast<uint32_t *>(s_len)[threadIdx.x] =
+            reinterpret_cast<const uint32_t *>(p.len8)[threadIdx.x];
     __syncthreads();
     const uint32_t tile = blockIdx.x;
     const uint64_t base = (uint64_t)tile * ENC_TILE;
@@ -481,7 +524,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
         enc_load_raw<true>(p, base + t0, vcnt, raw);
     else
         enc_load_raw<false>(p, base + t0, vcnt, raw);
-    uint32_t sum = enc_sum_lens(raw, vcnt, s_tab);
+    uint32_t sum = enc_sum_lens<false>(raw, vcnt, s_len);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1)
         sum += __shfl_xor(sum, d, 64);
@@ -605,7 +648,7 @@ __device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, 
 // symbols that follow it (last pass only) and copy the pass's words out with
 // coalesced byte-swapped 16-byte stores, clearing the image on the way.
 __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *stg, uint32_t *s_ctl,
-                                                const uint32_t *s_tab, uint32_t la_sym,
+                                                const uint2 *s_tab, uint32_t la_sym,
                                                 uint64_t tile_end, uint64_t E, uint64_t gbase,
                                                 uint64_t g0, uint64_t g1, uint32_t endbit,
                                                 uint32_t need, uint32_t nwords, uint32_t wlo)
@@ -637,8 +680,6 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
         *reinterpret_cast<uint4 *>(stg + j) = make_uint4(0, 0, 0, 0);
         const uint32_t vals[4] = {bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)};
         const uint64_t b = u << 4;
-        if (p.debug & 4u)
-            continue;
         if ((u << 2) >= ga && (u << 2) + 4 <= gb && b + 16 <= limit && b + 16 <= p.out_cap &&
             p.out_aligned16) {
             *reinterpret_cast<uint4 *>(p.out + b) = make_uint4(vals[0], vals[1], vals[2], vals[3]);
@@ -689,17 +730,19 @@ template <int G, bool CHAINED, bool FULL>
 __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(EncParams p)
 {
     __shared__ __align__(16) uint32_t stg[ENC_WINW];
-    __shared__ uint32_t s_tab[256 * ENC_REPL];
+    __shared__ uint2 s_tab[256 * ENC_REPL];
+    __shared__ __align__(16) uint8_t s_len[256];
+    __shared__ uint32_t s_dump[ENC_THREADS]; // per-lane don't-care slots of the flat sink
     __shared__ uint32_t s_toff[ENC_BATCH][ENC_THREADS + 1];
     __shared__ uint32_t s_wave[ENC_BATCH][ENC_WAVES];
     __shared__ uint64_t s_start;
     __shared__ uint32_t s_ctl[2];
     __shared__ uint32_t s_batch;
 
-    enc_stage_table(p, s_tab);
+    enc_stage_table(p, s_tab, s_len);
     if (CHAINED) {
         if (threadIdx.x == 0)
-            s_batch = p.first_batch + atomicAdd(p.ticket, 1u);
+            s_batch = p.first_batch + ((p.debug & 4u) ? blockIdx.x : atomicAdd(p.ticket, 1u));
     }
     for (uint32_t i = threadIdx.x; i < ENC_WINW / 4; i += ENC_THREADS)
         reinterpret_cast<uint4 *>(stg)[i] = make_uint4(0, 0, 0, 0);
@@ -732,7 +775,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
     uint32_t nbits[ENC_BATCH], incl[ENC_BATCH];
 #pragma unroll
     for (int t = 0; t < ENC_BATCH; ++t) {
-        nbits[t] = (p.debug & 16u) ? 64u + (raw[t][0] & 1u) : enc_sum_lens(raw[t], vcnt[t], s_tab);
+        nbits[t] = enc_sum_lens<FULL>(raw[t], vcnt[t], s_len);
         incl[t] = wave_incl_scan(nbits[t]);
         if (lane == 63)
             s_wave[t][wv] = incl[t];
@@ -802,20 +845,12 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
         // the table is read again here on purpose: without this fence the
         // compiler keeps all of stage A's lookups alive (in scratch) instead
         asm volatile("" ::: "memory");
-        uint32_t rc[ENC_SPT / 4];
+        uint32_t vc = 0, la = 0;
 #pragma unroll
-        for (int j = 0; j < ENC_SPT / 4; ++j) {
-            uint32_t v = raw[ENC_BATCH - 1][j];
-#pragma unroll
-            for (int u = ENC_BATCH - 2; u >= 0; --u)
-                v = t == (uint32_t)u ? raw[u][j] : v;
-            rc[j] = v;
-        }
-        uint32_t vc = vcnt[ENC_BATCH - 1], la = la_sym[ENC_BATCH - 1];
-#pragma unroll
-        for (int u = ENC_BATCH - 2; u >= 0; --u) {
-            vc = t == (uint32_t)u ? vcnt[u] : vc;
-            la = t == (uint32_t)u ? la_sym[u] : la;
+        for (int u = 0; u < ENC_BATCH; ++u) {
+            const uint32_t m = 0u - (uint32_t)(t == (uint32_t)u);
+            vc |= vcnt[u] & m;
+            la |= la_sym[u] & m;
         }
         const uint64_t base = (uint64_t)tile * ENC_TILE;
         const uint64_t left = p.n - base;
@@ -856,7 +891,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
             if (nwords <= ENC_WINW) {
                 // common case, straight-line: the whole tile fits one image pass
                 if (my_bits && !(p.debug & 2u))
-                    enc_pack_thread<G>(p, rc, vc, s_tab, stg, s_lo + toff);
+                    enc_pack_thread<G, FULL>(p, raw, t, vc, s_tab, stg, s_dump, s_lo + toff);
                 enc_finish_pass(p, stg, s_ctl, s_tab, la, tile_end, E, gbase, g0, g1, endbit, need,
                                 nwords, 0);
             } else {
@@ -1380,7 +1415,8 @@ struct hf_model {
     hf_ctx *ctx = nullptr;
     void *d_blob = nullptr;
     uint64_t *d_enc = nullptr;   // 256 x (code << 6 | len)
-    uint32_t *d_enc32 = nullptr; // 256 x (code << 6 | len), or ENC_LONG_FLAG | len
+    uint2 *d_enc2 = nullptr;     // 256 x {code, len} ({0, ENC_LONG_FLAG | len} above 32 bits)
+    uint8_t *d_len8 = nullptr;   // 256 x len
     uint16_t *d_lut = nullptr;
     uint64_t *d_keys = nullptr;
     uint8_t *d_ksyms = nullptr;
@@ -1444,12 +1480,13 @@ int flags_to_status(hf_ctx *ctx, uint64_t flags)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or null*/,
-                 const uint32_t *enc_tab32, const hf::DecodeLut &lut, const uint64_t *keys,
+                 const uint32_t *enc_tab2 /*512*/, const hf::DecodeLut &lut, const uint64_t *keys,
                  const uint8_t *syms, const uint8_t *klens, uint64_t m)
 {
     const size_t off_enc = 0;
-    const size_t off_enc32 = off_enc + 256 * sizeof(uint64_t);
-    const size_t off_lut = align_up(off_enc32 + 256 * sizeof(uint32_t), 16);
+    const size_t off_enc2 = off_enc + 256 * sizeof(uint64_t);
+    const size_t off_len8 = off_enc2 + 512 * sizeof(uint32_t);
+    const size_t off_lut = align_up(off_len8 + 256, 16);
     const size_t off_keys = align_up(off_lut + lut.pool.size() * 2, 16);
     const size_t off_ksyms = off_keys + 256 * sizeof(uint64_t);
     const size_t off_klens = off_ksyms + 256;
@@ -1457,7 +1494,9 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     std::vector<uint8_t> blob(total, 0);
     if (enc_tab) {
         std::memcpy(blob.data() + off_enc, enc_tab, 256 * sizeof(uint64_t));
-        std::memcpy(blob.data() + off_enc32, enc_tab32, 256 * sizeof(uint32_t));
+        std::memcpy(blob.data() + off_enc2, enc_tab2, 512 * sizeof(uint32_t));
+        for (int i = 0; i < 256; ++i)
+            blob[off_len8 + i] = (uint8_t)(enc_tab[i] & 63u);
     }
     std::memcpy(blob.data() + off_lut, lut.pool.data(), lut.pool.size() * 2);
     std::memcpy(blob.data() + off_keys, keys, m * sizeof(uint64_t));
@@ -1467,7 +1506,8 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     HF_HIP(ctx, hipMemcpy(mod->d_blob, blob.data(), total, hipMemcpyHostToDevice));
     uint8_t *b = static_cast<uint8_t *>(mod->d_blob);
     mod->d_enc = reinterpret_cast<uint64_t *>(b + off_enc);
-    mod->d_enc32 = reinterpret_cast<uint32_t *>(b + off_enc32);
+    mod->d_enc2 = reinterpret_cast<uint2 *>(b + off_enc2);
+    mod->d_len8 = b + off_len8;
     mod->d_lut = reinterpret_cast<uint16_t *>(b + off_lut);
     mod->d_keys = reinterpret_cast<uint64_t *>(b + off_keys);
     mod->d_ksyms = b + off_ksyms;
@@ -1645,11 +1685,12 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
     if (maxlen == 0)
         return fail(ctx, HF_ERR_EMPTY, "model has no symbol with a code");
     uint64_t enc[256];
-    uint32_t enc32[256];
+    uint32_t enc2[512];
     for (int i = 0; i < 256; ++i) {
         enc[i] = (codes[i] << 6) | lens[i];
-        enc32[i] = lens[i] <= ENC_PACKED_MAXLEN ? (uint32_t)enc[i]
-                                                : (ENC_LONG_FLAG | (uint32_t)lens[i]);
+        const bool fits = lens[i] <= ENC_PACKED_MAXLEN;
+        enc2[2 * i + 0] = fits ? (uint32_t)codes[i] : 0u;
+        enc2[2 * i + 1] = fits ? (uint32_t)lens[i] : (ENC_LONG_FLAG | (uint32_t)lens[i]);
     }
     uint64_t keys[256], m = 0;
     uint8_t syms[256], klens[256];
@@ -1666,7 +1707,7 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
     mod->ctx = ctx;
     mod->maxlen = (uint32_t)maxlen;
     mod->has_encode = true;
-    rc = upload_model(ctx, mod, enc, enc32, lut, keys, syms, klens, m);
+    rc = upload_model(ctx, mod, enc, enc2, lut, keys, syms, klens, m);
     if (rc != HF_OK) {
         delete mod;
         return rc;
@@ -1780,7 +1821,8 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     p.in = d_in;
     p.n = n;
     p.tab = model->d_enc;
-    p.tab32 = model->d_enc32;
+    p.tab2 = model->d_enc2;
+    p.len8 = model->d_len8;
     p.out = d_out;
     p.out_cap = out_cap;
     p.lead_bits = lead_bits;
@@ -1793,7 +1835,7 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     p.result = d_result;
     p.n_tiles = n_tiles;
     p.timeout_ticks = (uint64_t)ctx->timeout_ms * 100000ull;
-    p.debug = (uint32_t)ctx->debug;
+    p.debug = (uint32_t)ctx->debug & 31u;
 
     const size_t need = ((size_t)n_tiles + 4) * sizeof(uint64_t);
     int rc = ensure_scratch(ctx, need);

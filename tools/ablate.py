@@ -24,8 +24,8 @@ def run(mode, dbg, reps=5):
         hd.encode_async(data, model, bufs)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-names = {0: "full", 1: "stageA+lookback only", 2: "no pack", 8: "no lookback", 9: "stageA only (no lookback)",
-         32: "plain store instead of ds_or", 64: "no emit", 128: "no table lookup in pack", 192: "no emit, no lookup"}
+names = {0: "full", 4: "full, blockIdx as ticket", 9: "stageA only (no lookback)", 13: "stageA only, blockIdx ticket",
+         1: "stageA+lookback", 5: "stageA+lookback, blockIdx ticket"}
 for mode in (1,):
     for dbg, name in names.items():
         print(f"mode {mode} debug {dbg:2d} {name:28s} {run(mode, dbg):.3f} ms", flush=True)

@@ -7,7 +7,7 @@ from huffman_amd import device as hd, synth
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-cs = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+cs = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 n = mib << 20
 data = synth.generate_device(kind, n, seed=2024)
