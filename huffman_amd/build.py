@@ -11,6 +11,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhfgpu.so")
 SOURCES = [os.path.join(CSRC, "hfgpu.hip"), os.path.join(CSRC, "codebook.cpp")]
 HEADERS = [os.path.join(ROOT, "include", "hfgpu.h"), os.path.join(CSRC, "hfgpu_internal.h")]
+# host programs on top of the C++ mirror (include/hfgpu.hpp): (source, executable)
+PROGRAMS = [
+    (os.path.join(HERE, "cli", "main.cpp"), os.path.join(HERE, "bin", "hfgpu")),
+    (os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp"),
+     os.path.join(ROOT, "tests", "cpp", "test_mirror")),
+]
 
 
 def hipcc() -> str:
@@ -27,8 +33,35 @@ def stale() -> bool:
     return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
 
 
+def build_programs(force: bool = False, verbose: bool = False) -> list[str]:
+    """Host-only C++ programs; they reach the GPU through libhfgpu.so alone."""
+    hpp = os.path.join(ROOT, "include", "hfgpu.hpp")
+    out = []
+    for src, exe in PROGRAMS:
+        out.append(exe)
+        deps = [src, hpp, LIB, *HEADERS]
+        if not force and os.path.exists(exe) and all(
+                os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
+            continue
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        obj = exe + ".o"
+        rel = os.path.relpath(HERE, os.path.dirname(exe))
+        cmds = [
+            ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-c", src,
+             "-o", obj],
+            [hipcc(), obj, "-o", exe, "-L" + HERE, "-lhfgpu", "-Wl,-rpath,$ORIGIN/" + rel],
+        ]
+        for cmd in cmds:
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        os.remove(obj)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
+        build_programs(False, verbose)
         return LIB
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     common = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
@@ -42,6 +75,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    build_programs(True, verbose)
     return LIB
 
 

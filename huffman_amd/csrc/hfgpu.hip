@@ -1409,6 +1409,8 @@ struct hf_ctx {
     int hist_grid = 0;
     int timeout_ms = 2000;
     int debug = 0;
+    void *arena = nullptr; // device staging of the *_host entry points (grow only)
+    size_t arena_bytes = 0;
 };
 
 struct hf_model {
@@ -1463,6 +1465,22 @@ int ensure_scratch(hf_ctx *ctx, size_t bytes)
     size_t want = std::max(bytes, (size_t)1 << 20);
     HF_HIP(ctx, hipMalloc(&ctx->scratch, want));
     ctx->scratch_bytes = want;
+    return HF_OK;
+}
+
+int ensure_arena(hf_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->arena_bytes)
+        return HF_OK;
+    if (ctx->arena) {
+        HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        HF_HIP(ctx, hipFree(ctx->arena));
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HF_HIP(ctx, hipMalloc(&ctx->arena, want));
+    ctx->arena_bytes = want;
     return HF_OK;
 }
 
@@ -1582,6 +1600,8 @@ int hf_ctx_destroy(hf_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch)
         (void)hipFree(ctx->scratch);
+    if (ctx->arena)
+        (void)hipFree(ctx->arena);
     if (ctx->d_result)
         (void)hipFree(ctx->d_result);
     delete ctx;
@@ -2052,6 +2072,125 @@ int hf_decode_serial(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, ui
     HF_HIP(ctx, hipMemcpyAsync(res, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return flags_to_status(ctx, res[HF_RES_FLAGS]);
+}
+
+// ------------------------------------------------------- host-buffer forms
+
+int hf_histogram_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n, uint64_t hist[256])
+{
+    if (!ctx || !hist || (!h_in && n))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram_host: null pointer");
+    int rc = ensure_arena(ctx, n + 16);
+    if (rc != HF_OK)
+        return rc;
+    if (n)
+        HF_HIP(ctx, hipMemcpyAsync(ctx->arena, h_in, n, hipMemcpyHostToDevice, ctx->stream));
+    return hf_histogram(ctx, static_cast<const uint8_t *>(ctx->arena), n, hist);
+}
+
+int hf_encode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint64_t n,
+                   uint32_t lead_bits, uint8_t *h_out, uint64_t out_cap, uint32_t chunk_syms,
+                   uint16_t *h_chunk_bits, uint64_t *h_seg_off, uint64_t *total_bits)
+{
+    if (!ctx || !model || (!h_in && n) || (!h_out && out_cap))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_host: null pointer");
+    if ((h_chunk_bits == nullptr) != (h_seg_off == nullptr))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_host: pass both gap arrays or neither");
+    uint64_t n_chunks = 0, n_segs = 0;
+    if (h_chunk_bits && hf_gap_layout(n, chunk_syms, &n_chunks, &n_segs) != HF_OK)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_host: chunk_syms must be 64, 128 or 256");
+    // arena layout: input | stream | chunk_bits | seg_off, each 256-byte aligned
+    const uint64_t bound = std::min<uint64_t>(hf_encode_bound(model, n, lead_bits),
+                                              (out_cap + 3) & ~3ull);
+    const size_t off_out = align_up(n + 16, 256);
+    const size_t off_cb = align_up(off_out + bound + 16, 256);
+    const size_t off_so = align_up(off_cb + n_chunks * 2 + 16, 256);
+    const size_t total = off_so + n_segs * 8 + 16;
+    int rc = ensure_arena(ctx, total);
+    if (rc != HF_OK)
+        return rc;
+    uint8_t *a = static_cast<uint8_t *>(ctx->arena);
+    if (n)
+        HF_HIP(ctx, hipMemcpyAsync(a, h_in, n, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t bits = 0;
+    rc = hf_encode(ctx, model, a, n, lead_bits, a + off_out, std::min<uint64_t>(bound, out_cap),
+                   chunk_syms, h_chunk_bits ? reinterpret_cast<uint16_t *>(a + off_cb) : nullptr,
+                   h_seg_off ? reinterpret_cast<uint64_t *>(a + off_so) : nullptr, &bits);
+    if (total_bits)
+        *total_bits = bits;
+    if (rc != HF_OK)
+        return rc;
+    const uint64_t nbytes = (lead_bits + bits + 7) / 8;
+    if (nbytes > out_cap)
+        return fail(ctx, HF_ERR_CAPACITY, "hf_encode_host: output buffer too small");
+    if (nbytes)
+        HF_HIP(ctx, hipMemcpyAsync(h_out, a + off_out, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_chunk_bits && n_chunks) {
+        HF_HIP(ctx, hipMemcpyAsync(h_chunk_bits, a + off_cb, n_chunks * 2, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HF_HIP(ctx, hipMemcpyAsync(h_seg_off, a + off_so, n_segs * 8, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    }
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HF_OK;
+}
+
+int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint64_t in_bytes,
+                   uint64_t n_out, uint32_t chunk_syms, const uint16_t *h_chunk_bits,
+                   const uint64_t *h_seg_off, uint8_t *h_out)
+{
+    if (!ctx || !model || (!h_in && in_bytes) || (!h_out && n_out))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_host: null pointer");
+    if ((h_chunk_bits == nullptr) != (h_seg_off == nullptr))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_host: pass both gap arrays or neither");
+    uint64_t n_chunks = 0, n_segs = 0;
+    if (h_chunk_bits && hf_gap_layout(n_out, chunk_syms, &n_chunks, &n_segs) != HF_OK)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_host: chunk_syms must be 64, 128 or 256");
+    const size_t off_out = align_up(in_bytes + 16, 256);
+    const size_t off_cb = align_up(off_out + n_out + 16, 256);
+    const size_t off_so = align_up(off_cb + n_chunks * 2 + 16, 256);
+    const size_t total = off_so + n_segs * 8 + 16;
+    int rc = ensure_arena(ctx, total);
+    if (rc != HF_OK)
+        return rc;
+    uint8_t *a = static_cast<uint8_t *>(ctx->arena);
+    if (in_bytes)
+        HF_HIP(ctx, hipMemcpyAsync(a, h_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (h_chunk_bits && n_chunks) {
+        HF_HIP(ctx, hipMemcpyAsync(a + off_cb, h_chunk_bits, n_chunks * 2, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        HF_HIP(ctx, hipMemcpyAsync(a + off_so, h_seg_off, n_segs * 8, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        rc = hf_decode(ctx, model, a, in_bytes, 0, n_out, chunk_syms,
+                       reinterpret_cast<const uint16_t *>(a + off_cb),
+                       reinterpret_cast<const uint64_t *>(a + off_so), a + off_out);
+    } else {
+        rc = hf_decode_serial(ctx, model, a, in_bytes, 0, n_out, a + off_out);
+    }
+    if (rc != HF_OK)
+        return rc;
+    if (n_out)
+        HF_HIP(ctx, hipMemcpyAsync(h_out, a + off_out, n_out, hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HF_OK;
+}
+
+int hf_encoder_write_value_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n,
+                                const uint64_t codes[256], const uint64_t lens[256],
+                                uint64_t state[3], uint64_t *ret)
+{
+    if (!ctx || (!h_in && n))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encoder_write_value_host: null pointer");
+    if (n > HF_WRITE_VALUE_MAX)
+        return fail(ctx, HF_ERR_UNSUPPORTED, "hf_encoder_write_value_host: more than %llu symbols",
+                    (unsigned long long)HF_WRITE_VALUE_MAX);
+    int rc = ensure_arena(ctx, n + 16);
+    if (rc != HF_OK)
+        return rc;
+    if (n)
+        HF_HIP(ctx, hipMemcpyAsync(ctx->arena, h_in, n, hipMemcpyHostToDevice, ctx->stream));
+    return hf_encoder_write_value(ctx, static_cast<const uint8_t *>(ctx->arena), n, codes, lens,
+                                  state, ret);
 }
 
 } // extern "C"

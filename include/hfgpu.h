@@ -200,6 +200,27 @@ HF_API int hf_decode_serial(hf_ctx *ctx, const hf_model *model, const uint8_t *d
                             uint64_t in_bytes, uint64_t bit_base, uint64_t n_out,
                             uint8_t *d_out);
 
+/* ------------------------------------------------------- host-buffer forms
+ *
+ * The same operations for callers whose data lives in host memory (what a
+ * `&[u8]` / `Vec<u8>` binding passes): the library stages the buffers through
+ * a device arena owned by the context (grow only, reused between calls),
+ * copies over PCIe, runs the device entry point on the context's stream and
+ * synchronises.  Gap arrays are optional; without them hf_decode_host falls
+ * back to the sequential device walk. */
+HF_API int hf_histogram_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n, uint64_t hist[256]);
+HF_API int hf_encode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint64_t n,
+                          uint32_t lead_bits, uint8_t *h_out, uint64_t out_cap,
+                          uint32_t chunk_syms, uint16_t *h_chunk_bits, uint64_t *h_seg_off,
+                          uint64_t *total_bits);
+HF_API int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in,
+                          uint64_t in_bytes, uint64_t n_out, uint32_t chunk_syms,
+                          const uint16_t *h_chunk_bits, const uint64_t *h_seg_off,
+                          uint8_t *h_out);
+HF_API int hf_encoder_write_value_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n,
+                                       const uint64_t codes[256], const uint64_t lens[256],
+                                       uint64_t state[3], uint64_t *ret);
+
 #ifdef __cplusplus
 }
 #endif

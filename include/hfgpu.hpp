@@ -1,0 +1,845 @@
+// Host-side C++ mirror of the public API of the rscompress-huffman crate, on
+// top of the C ABI in hfgpu.h.  Same names, argument meaning and error
+// behaviour as the reference (file:line cited per item); every byte of compute
+// runs in libhfgpu.so on the GPU -- there is no CPU codec in here.
+//
+// Rust -> C++ conventions: `usize` is std::uint64_t; panics (`expect`,
+// `unwrap`, index underflow) become Panic exceptions; io::Error becomes
+// IoError (InvalidData keeps its kind); `impl Write` / `impl Read` are
+// duck-typed template parameters:
+//     Writer:  std::size_t write(const std::uint8_t*, std::size_t);  void flush();
+//     Reader:  std::size_t read(std::uint8_t*, std::size_t);          (0 = end)
+#ifndef HFGPU_HPP
+#define HFGPU_HPP
+
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <istream>
+#include <map>
+#include <memory>
+#include <optional>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "hfgpu.h"
+
+namespace rscompress_huffman {
+
+using usize = std::uint64_t;
+using u8 = std::uint8_t;
+
+constexpr std::size_t BUF = 4096; // src/lib.rs:23
+
+struct Panic : std::runtime_error {
+    int status;
+    Panic(int st, const std::string &what) : std::runtime_error(what), status(st) {}
+};
+struct IoError : std::runtime_error {
+    bool invalid_data; // io::ErrorKind::InvalidData (src/huffman/encode.rs:102-104)
+    IoError(bool inv, const std::string &what) : std::runtime_error(what), invalid_data(inv) {}
+};
+
+// One hf_ctx per process (device 0); created on first use.
+class Runtime {
+  public:
+    static hf_ctx *ctx()
+    {
+        static Runtime rt;
+        return rt.ctx_;
+    }
+    static void check(int status, const char *what)
+    {
+        if (status == HF_OK)
+            return;
+        std::string msg = std::string(what) + ": " + hf_strerror(status) + " (" +
+                          hf_last_error(ctx()) + ")";
+        if (status == HF_ERR_CODELEN)
+            throw IoError(true, "Codelen > 64");
+        throw Panic(status, msg);
+    }
+
+  private:
+    Runtime()
+    {
+        if (hf_ctx_create(0, &ctx_) != HF_OK)
+            throw Panic(HF_ERR_HIP, "hf_ctx_create failed: a GPU is required, there is no CPU path");
+    }
+    ~Runtime() { hf_ctx_destroy(ctx_); }
+    hf_ctx *ctx_ = nullptr;
+};
+
+// ------------------------------------------------------------ src/model.rs
+
+// trait Model (src/model.rs:3-7)
+struct Model {
+    virtual ~Model() = default;
+    virtual std::pair<usize, usize> encode(u8 sym) const = 0;
+    virtual usize sentinel() const = 0;
+    virtual std::map<usize, std::pair<u8, u8>> to_btreemap() const = 0;
+};
+
+// ------------------------------------------------------------ src/stats.rs
+
+namespace stats {
+
+// generate_histogram (src/stats.rs:13-28): the reader is drained in BUF-sized
+// reads; the counting itself runs on the GPU.
+template <class Reader>
+std::array<usize, 256> generate_histogram(Reader &reader)
+{
+    std::vector<u8> all;
+    std::vector<u8> buffer(BUF);
+    while (true) {
+        const std::size_t n = reader.read(buffer.data(), buffer.size());
+        if (n == 0)
+            break;
+        all.insert(all.end(), buffer.begin(), buffer.begin() + n);
+    }
+    std::array<usize, 256> hist{};
+    Runtime::check(hf_histogram_host(Runtime::ctx(), all.data(), all.size(), hist.data()),
+                   "generate_histogram");
+    return hist;
+}
+
+// generate_random_byte_vector (src/stats.rs:36-42).  The reference draws from
+// an unseeded thread_rng; a seed can be given here to make data reproducible.
+inline std::vector<u8> generate_random_byte_vector(u8 min, u8 max, usize count,
+                                                   const std::vector<u8> &weights,
+                                                   std::uint64_t seed = std::random_device{}())
+{
+    if ((usize)(max - min) != weights.size())
+        throw Panic(HF_ERR_BAD_ARG, "assertion failed: choices.len() == weights.len()");
+    std::mt19937_64 rng(seed);
+    std::discrete_distribution<int> dist(weights.begin(), weights.end());
+    std::vector<u8> out(count);
+    for (auto &b : out)
+        b = (u8)(min + dist(rng));
+    return out;
+}
+
+} // namespace stats
+
+// ------------------------------------------------------ src/huffman/mod.rs
+
+namespace huffman {
+
+// calculate_codeword_length_inplace (src/huffman/mod.rs:71-125)
+inline void calculate_codeword_length_inplace(std::vector<usize> &histogram)
+{
+    const int rc = hf_codeword_lengths_inplace(histogram.data(), histogram.size());
+    if (rc != HF_OK)
+        throw Panic(rc, "attempt to subtract with overflow (empty histogram)");
+}
+
+// sort_by_value (src/huffman/mod.rs:127-141)
+inline std::vector<std::pair<usize, usize>> sort_by_value(const std::vector<usize> &store)
+{
+    usize idx[256], cnt[256], m = 0;
+    const int rc = hf_sort_by_value(store.data(), store.size(), idx, cnt, &m);
+    if (rc != HF_OK)
+        throw Panic(rc, "assertion failed: store.len() <= 256");
+    std::vector<std::pair<usize, usize>> out;
+    for (usize i = 0; i < m; ++i)
+        out.emplace_back(idx[i], cnt[i]);
+    return out;
+}
+
+// extract_values (src/huffman/mod.rs:150-153)
+inline std::vector<usize> extract_values(const std::vector<std::pair<usize, usize>> &store)
+{
+    std::vector<usize> v;
+    for (auto &p : store)
+        v.push_back(p.second);
+    return v;
+}
+
+// calculate_codewords_based_on_length (src/huffman/mod.rs:155-171)
+inline std::pair<std::vector<usize>, std::vector<usize>>
+calculate_codewords_based_on_length(const std::vector<usize> &lengths)
+{
+    std::vector<usize> small_codes(lengths.size()), big_codes(lengths.size());
+    const int rc = hf_codewords_from_lengths(lengths.data(), lengths.size(), small_codes.data(),
+                                             big_codes.data());
+    if (rc != HF_OK)
+        throw Panic(rc, "calculate_codewords_based_on_length: bad lengths");
+    return {small_codes, big_codes};
+}
+
+// generate_extended_codewords (src/huffman/mod.rs:181-206)
+inline std::pair<std::array<usize, 256>, std::array<usize, 256>>
+generate_extended_codewords(const std::vector<usize> &histogram)
+{
+    std::array<usize, 256> codes{}, lens{};
+    const int rc = hf_build_codebook(histogram.data(), histogram.size(), codes.data(), lens.data());
+    if (rc != HF_OK)
+        throw Panic(rc, "generate_extended_codewords: empty or oversized histogram");
+    return {codes, lens};
+}
+
+// struct Huffman (src/huffman/mod.rs:10-13) + impl Model (:15-39) + ctors (:44-66)
+class Huffman : public Model {
+  public:
+    Huffman(const std::array<usize, 256> &codewords, const std::array<usize, 256> &length)
+        : codewords_(codewords), length_(length)
+    {
+    }
+    static Huffman from_histogram(const std::array<usize, 256> &histogram)
+    {
+        auto cl = generate_extended_codewords(
+            std::vector<usize>(histogram.begin(), histogram.end()));
+        return Huffman(cl.first, cl.second);
+    }
+    template <class SeekReader>
+    static Huffman from_reader(SeekReader &reader)
+    {
+        auto hist = stats::generate_histogram(reader);
+        reader.rewind(); // reader.seek(SeekFrom::Start(0)), mod.rs:54-56
+        return from_histogram(hist);
+    }
+    static Huffman from_slice(const u8 *data, usize n)
+    {
+        std::array<usize, 256> hist{};
+        Runtime::check(hf_histogram_host(Runtime::ctx(), data, n, hist.data()), "from_slice");
+        return from_histogram(hist);
+    }
+    static Huffman from_slice(const std::vector<u8> &data)
+    {
+        return from_slice(data.data(), data.size());
+    }
+
+    std::pair<usize, usize> encode(u8 sym) const override
+    {
+        return {codewords_[sym], length_[sym]};
+    }
+    usize sentinel() const override { return hf_model_sentinel(length_.data()); }
+    std::map<usize, std::pair<u8, u8>> to_btreemap() const override
+    {
+        usize keys[256], m = 0;
+        u8 syms[256], klens[256];
+        const int rc = hf_model_to_table(codewords_.data(), length_.data(), keys, syms, klens, &m);
+        if (rc != HF_OK)
+            throw Panic(rc, "to_btreemap");
+        std::map<usize, std::pair<u8, u8>> bt;
+        for (usize i = 0; i < m; ++i)
+            bt[keys[i]] = {syms[i], klens[i]};
+        return bt;
+    }
+    const std::array<usize, 256> &codewords() const { return codewords_; }
+    const std::array<usize, 256> &length() const { return length_; }
+
+  private:
+    std::array<usize, 256> codewords_, length_;
+};
+
+// Device-resident tables of a Model (hf_model), built on demand.
+class DeviceModel {
+  public:
+    explicit DeviceModel(const Model &m)
+    {
+        std::array<usize, 256> codes{}, lens{};
+        for (int s = 0; s < 256; ++s) {
+            auto cl = m.encode((u8)s);
+            codes[s] = cl.first;
+            lens[s] = cl.second;
+        }
+        Runtime::check(hf_model_create(Runtime::ctx(), codes.data(), lens.data(), &h_),
+                       "Huffman model");
+        codes_ = codes;
+        lens_ = lens;
+    }
+    DeviceModel(const std::map<usize, std::pair<u8, u8>> &btree, usize sentinel)
+    {
+        std::vector<usize> keys;
+        std::vector<u8> syms, klens;
+        for (auto &kv : btree) {
+            keys.push_back(kv.first);
+            syms.push_back(kv.second.first);
+            klens.push_back(kv.second.second);
+        }
+        Runtime::check(hf_model_from_table(Runtime::ctx(), keys.data(), syms.data(), klens.data(),
+                                           keys.size(), sentinel, &h_),
+                       "decode table");
+    }
+    ~DeviceModel() { hf_model_destroy(h_); }
+    DeviceModel(const DeviceModel &) = delete;
+    DeviceModel &operator=(const DeviceModel &) = delete;
+    hf_model *handle() const { return h_; }
+    const std::array<usize, 256> &codes() const { return codes_; }
+    const std::array<usize, 256> &lens() const { return lens_; }
+
+  private:
+    hf_model *h_ = nullptr;
+    std::array<usize, 256> codes_{}, lens_{};
+};
+
+// Side metadata of a stream written by Encoder: the gap array.
+struct GapArray {
+    std::uint32_t chunk_syms = 64;
+    std::vector<std::uint16_t> chunk_bits;
+    std::vector<usize> seg_off;
+    usize symbols = 0; // symbols covered
+};
+
+// -------------------------------------------------- src/huffman/encode.rs
+
+namespace encode {
+
+// calculate_length (src/huffman/encode.rs:140-149)
+inline usize calculate_length(usize val) { return hf_calculate_length(val); }
+
+// struct Encoder<'a, W: Write, M: Model> (src/huffman/encode.rs:26-34).
+// write() stages the input; the GPU encodes when `flush()` is called (or when
+// STAGE_LIMIT bytes are pending): the reference's progressive inner writes
+// are not observable in the final stream.  The return value of write() and
+// `writeout` between calls follow the reference's put/cleanup schedule
+// exactly while `track_write_value` is set and calls carry at most
+// HF_WRITE_VALUE_MAX symbols (a device lane replays the automaton, one small
+// launch per call).  Otherwise write() returns the bytes it really handed to
+// `inner` during the call (0 while staging) and `writeout` is exact again
+// after flush().  Callers that ignore the return value, like the file
+// compressor below, clear the flag.
+template <class W>
+class Encoder {
+  public:
+    static constexpr std::size_t STAGE_LIMIT = std::size_t(1) << 30;
+
+    W inner;
+    const Model *model;
+    std::optional<u8> fillbits; // set by flush (encode.rs:130)
+    usize readbytes = 0;
+    usize writeout = 0;
+    bool track_write_value = true;
+
+    Encoder(W writer, const Model &m) : inner(std::move(writer)), model(&m) {} // encode.rs:39-49
+    std::vector<u8> magic() const { return {'p', 'z', 'h', 'f'}; }             // encode.rs:51-53
+    void plain_write(const u8 *bytes, std::size_t n) { write_all(bytes, n); }  // encode.rs:54-56
+    void plain_write(const std::vector<u8> &b) { write_all(b.data(), b.size()); }
+
+    // impl Write::write (encode.rs:91-116)
+    usize write(const u8 *buf, std::size_t n)
+    {
+        ensure_device_model();
+        usize ret = 0;
+        const bool replay = track_write_value && n <= HF_WRITE_VALUE_MAX;
+        if (replay) {
+            usize state[3] = {auto_buffer_, auto_remaining_, auto_writeout_};
+            Runtime::check(hf_encoder_write_value_host(Runtime::ctx(), buf, n, dm_->codes().data(),
+                                                       dm_->lens().data(), state, &ret),
+                           "Encoder::write");
+            auto_buffer_ = state[0];
+            auto_remaining_ = state[1];
+            auto_writeout_ = state[2];
+            writeout = auto_writeout_;
+        } else {
+            track_write_value = false;
+        }
+        readbytes += n;
+        pending_.insert(pending_.end(), buf, buf + n);
+        const usize before = emitted_;
+        if (pending_.size() >= STAGE_LIMIT)
+            drain(false);
+        return replay ? ret : emitted_ - before;
+    }
+    usize write(const std::vector<u8> &buf) { return write(buf.data(), buf.size()); }
+
+    // impl Write::flush (encode.rs:118-136); like the reference it does not
+    // reset the encoder.
+    void flush()
+    {
+        ensure_device_model();
+        drain(true);
+        inner.flush();
+    }
+
+    const GapArray &gap() const { return gap_; }
+    const DeviceModel &device_model()
+    {
+        ensure_device_model();
+        return *dm_;
+    }
+
+  private:
+    void ensure_device_model()
+    {
+        if (!dm_)
+            dm_ = std::make_unique<DeviceModel>(*model);
+    }
+    void write_all(const u8 *b, std::size_t n)
+    {
+        std::size_t off = 0;
+        while (off < n) {
+            const std::size_t k = inner.write(b + off, n - off);
+            if (k == 0)
+                throw IoError(false, "failed to write whole buffer");
+            off += k;
+        }
+    }
+    // Encodes what is staged.  Whole bytes go to `inner`; when !final the last
+    // partial byte is kept and merged into the next batch (lead bits).
+    void drain(bool final)
+    {
+        const std::uint32_t lead = (std::uint32_t)(total_bits_ % 8);
+        const usize seg_syms = (usize)HF_SEG_CHUNKS * gap_.chunk_syms;
+        const usize n = final ? pending_.size() : pending_.size() - pending_.size() % seg_syms;
+        if (n == 0 && !final)
+            return;
+        std::vector<u8> out(hf_encode_bound(dm_->handle(), n, lead) + 8);
+        usize nch = 0, nsg = 0;
+        hf_gap_layout(n, gap_.chunk_syms, &nch, &nsg);
+        std::vector<std::uint16_t> cb(nch);
+        std::vector<usize> so(nsg);
+        usize bits = 0;
+        Runtime::check(hf_encode_host(Runtime::ctx(), dm_->handle(), pending_.data(), n, lead,
+                                      out.data(), out.size(), gap_.chunk_syms,
+                                      n ? cb.data() : nullptr, n ? so.data() : nullptr, &bits),
+                       "Encoder::flush");
+        // gap array: segment offsets become absolute; batches are only cut at
+        // multiples of a segment, so the arrays simply concatenate
+        const usize base_bit = total_bits_ - lead;
+        for (auto &v : so)
+            v += base_bit;
+        gap_.chunk_bits.insert(gap_.chunk_bits.end(), cb.begin(), cb.end());
+        gap_.seg_off.insert(gap_.seg_off.end(), so.begin(), so.end());
+        gap_.symbols += n;
+        usize nbytes = (lead + bits + 7) / 8;
+        if (lead && nbytes)
+            out[0] |= carry_;
+        total_bits_ += bits;
+        const bool partial = (total_bits_ % 8) != 0;
+        if (!final && partial && nbytes) {
+            carry_ = out[nbytes - 1];
+            --nbytes;
+        } else if (final) {
+            fillbits = (u8)((8 - total_bits_ % 8) % 8);
+        }
+        write_all(out.data(), nbytes);
+        emitted_ += nbytes;
+        if (!track_write_value || final)
+            writeout = (total_bits_ + 7) / 8;
+        pending_.erase(pending_.begin(), pending_.begin() + (std::ptrdiff_t)n);
+    }
+
+    std::unique_ptr<DeviceModel> dm_;
+    std::vector<u8> pending_;
+    GapArray gap_;
+    usize total_bits_ = 0, emitted_ = 0;
+    u8 carry_ = 0;
+    usize auto_buffer_ = 0, auto_remaining_ = 64, auto_writeout_ = 0; // encode.rs:43-47
+};
+
+} // namespace encode
+
+// --------------------------------------------------- src/huffman/header.rs
+
+namespace header {
+
+// struct Header (src/huffman/header.rs:9-15)
+struct Header {
+    std::vector<u8> magic;
+    std::map<usize, std::pair<u8, u8>> btree;
+    usize sentinel = 0;
+    usize readbytes = 0;
+
+    // impl From<&Encoder> (header.rs:22-31)
+    template <class W>
+    static Header from(const encode::Encoder<W> &enc)
+    {
+        Header h;
+        h.magic = enc.magic();
+        h.btree = enc.model->to_btreemap();
+        h.sentinel = enc.model->sentinel();
+        h.readbytes = enc.readbytes;
+        return h;
+    }
+    // to_binary (header.rs:39-43): bincode 1.x default options -- u64
+    // little-endian lengths and integers, map entries in key order.
+    std::vector<u8> to_binary() const
+    {
+        std::vector<u8> out;
+        auto le64 = [&](usize v) {
+            for (int i = 0; i < 8; ++i)
+                out.push_back((u8)(v >> (8 * i)));
+        };
+        le64(magic.size());
+        out.insert(out.end(), magic.begin(), magic.end());
+        le64(btree.size());
+        for (auto &kv : btree) {
+            le64(kv.first);
+            out.push_back(kv.second.first);
+            out.push_back(kv.second.second);
+        }
+        le64(sentinel);
+        le64(readbytes);
+        return out;
+    }
+    // from_binary (header.rs:44-46)
+    static Header from_binary(const u8 *p, std::size_t n)
+    {
+        std::size_t off = 0;
+        auto le64 = [&]() {
+            if (off + 8 > n)
+                throw Panic(HF_ERR_BAD_ARG, "called `Result::unwrap()` on an `Err` value: header");
+            usize v = 0;
+            for (int i = 0; i < 8; ++i)
+                v |= (usize)p[off + i] << (8 * i);
+            off += 8;
+            return v;
+        };
+        Header h;
+        const usize ml = le64();
+        if (off + ml > n)
+            throw Panic(HF_ERR_BAD_ARG, "header: truncated magic");
+        h.magic.assign(p + off, p + off + ml);
+        off += ml;
+        const usize cnt = le64();
+        for (usize i = 0; i < cnt; ++i) {
+            const usize key = le64();
+            if (off + 2 > n)
+                throw Panic(HF_ERR_BAD_ARG, "header: truncated table");
+            h.btree[key] = {p[off], p[off + 1]};
+            off += 2;
+        }
+        h.sentinel = le64();
+        h.readbytes = le64();
+        return h;
+    }
+    static Header from_binary(const std::vector<u8> &v) { return from_binary(v.data(), v.size()); }
+    void update_readbytes(std::uint64_t bytes) { readbytes = bytes; } // header.rs:47-49
+    bool operator==(const Header &o) const
+    {
+        return magic == o.magic && btree == o.btree && sentinel == o.sentinel &&
+               readbytes == o.readbytes;
+    }
+};
+
+} // namespace header
+
+// ------------------------------------------------ src/huffman/decode/mod.rs
+
+namespace decode {
+
+// prepare_lookup (decode/mod.rs:140-155): the values in key order plus the
+// sorted keys (the reference keeps them as a rank dictionary over a bit
+// vector; `rank1(v + 1) - 1` is the index of the largest key <= v).
+inline std::pair<std::vector<std::pair<u8, u8>>, std::vector<usize>>
+prepare_lookup(const std::map<usize, std::pair<u8, u8>> &bt)
+{
+    std::vector<std::pair<u8, u8>> table;
+    std::vector<usize> keys;
+    for (auto &kv : bt) {
+        keys.push_back(kv.first);
+        table.push_back(kv.second);
+    }
+    return {table, keys};
+}
+
+// search_key_or_next_small_key (decode/mod.rs:157-165)
+inline std::pair<u8, u8> search_key_or_next_small_key(const std::map<usize, std::pair<u8, u8>> &tree,
+                                                      usize key)
+{
+    auto it = tree.upper_bound(key);
+    if (it == tree.begin())
+        throw Panic(HF_ERR_DECODE, "Panic!!!!");
+    return std::prev(it)->second;
+}
+
+// read (decode/mod.rs:167-231): slice decoder.  Without a gap array the walk
+// is sequential on the device; pass the encoder's gap array for the
+// chunk-parallel kernel.
+inline std::vector<u8> read(const u8 *data, std::size_t n, const Model &model, usize goalsbyte,
+                            const GapArray *gap = nullptr)
+{
+    DeviceModel dm(model);
+    std::vector<u8> out(goalsbyte);
+    const bool use_gap = gap && gap->symbols >= goalsbyte && goalsbyte > 0;
+    Runtime::check(hf_decode_host(Runtime::ctx(), dm.handle(), data, n, goalsbyte,
+                                  use_gap ? gap->chunk_syms : 64,
+                                  use_gap ? gap->chunk_bits.data() : nullptr,
+                                  use_gap ? gap->seg_off.data() : nullptr, out.data()),
+                   "decode::read");
+    return out;
+}
+inline std::vector<u8> read(const std::vector<u8> &data, const Model &model, usize goalsbyte,
+                            const GapArray *gap = nullptr)
+{
+    return read(data.data(), data.size(), model, goalsbyte, gap);
+}
+
+// struct Decoder<R: Read> (decode/mod.rs:15-26): streaming decoder.  The
+// first read() drains the inner reader and decodes the whole stream on the
+// GPU; later calls are served from that buffer, so any read size (the
+// reference's example uses 15 bytes) costs a memcpy.
+template <class R>
+class Decoder {
+  public:
+    // Decoder::new (decode/mod.rs:29-47)
+    template <class W>
+    Decoder(R reader, encode::Encoder<W> &encoder)
+        : inner_(std::move(reader)), goalsbyte_(encoder.readbytes),
+          dm_(std::make_unique<DeviceModel>(*encoder.model)), gap_(encoder.gap())
+    {
+    }
+    // Decoder::from_header (decode/mod.rs:48-66)
+    Decoder(const header::Header &header, R reader, const GapArray *gap = nullptr)
+        : inner_(std::move(reader)), goalsbyte_(header.readbytes),
+          dm_(std::make_unique<DeviceModel>(header.btree, header.sentinel))
+    {
+        if (gap)
+            gap_ = *gap;
+    }
+    // impl Read::read (decode/mod.rs:70-137)
+    std::size_t read(u8 *buf, std::size_t len)
+    {
+        if (!decoded_)
+            decode_all();
+        const std::size_t k = std::min<std::size_t>(len, out_.size() - writeout_);
+        std::memcpy(buf, out_.data() + writeout_, k);
+        writeout_ += k;
+        return k;
+    }
+    std::size_t read_to_end(std::vector<u8> &dst)
+    {
+        if (!decoded_)
+            decode_all();
+        const std::size_t k = out_.size() - writeout_;
+        dst.insert(dst.end(), out_.begin() + writeout_, out_.end());
+        writeout_ = out_.size();
+        return k;
+    }
+
+  private:
+    void decode_all()
+    {
+        std::vector<u8> comp, chunk(1 << 16);
+        while (true) {
+            const std::size_t n = inner_.read(chunk.data(), chunk.size());
+            if (n == 0)
+                break;
+            comp.insert(comp.end(), chunk.begin(), chunk.begin() + n);
+        }
+        out_.resize(goalsbyte_);
+        const bool use_gap = gap_.symbols >= goalsbyte_ && goalsbyte_ > 0;
+        Runtime::check(hf_decode_host(Runtime::ctx(), dm_->handle(), comp.data(), comp.size(),
+                                      goalsbyte_, gap_.chunk_syms,
+                                      use_gap ? gap_.chunk_bits.data() : nullptr,
+                                      use_gap ? gap_.seg_off.data() : nullptr, out_.data()),
+                       "Decoder::read");
+        decoded_ = true;
+    }
+    R inner_;
+    usize goalsbyte_;
+    std::unique_ptr<DeviceModel> dm_;
+    GapArray gap_;
+    std::vector<u8> out_;
+    std::size_t writeout_ = 0;
+    bool decoded_ = false;
+};
+
+// vault::Decoder (decode/vault.rs:28-39,65-86): the reference's experimental
+// third decoder.  Only its results are reproduced (same bytes as Decoder);
+// its precondition `sentinel <= 8` (vault.rs:52-56) is kept.
+namespace vault {
+template <class R>
+class Decoder {
+  public:
+    Decoder(R reader, const Model &model, std::uint64_t output)
+        : inner_(std::move(reader)), remaining_(output)
+    {
+        if (model.sentinel() > 8)
+            throw Panic(HF_ERR_UNSUPPORTED, "assertion failed: sentinel <= 8");
+        header::Header h;
+        h.btree = model.to_btreemap();
+        h.sentinel = model.sentinel();
+        h.readbytes = output;
+        dec_ = std::make_unique<decode::Decoder<R>>(h, std::move(inner_));
+    }
+    std::size_t read(u8 *buf, std::size_t len) { return dec_->read(buf, len); }
+    std::size_t read_to_end(std::vector<u8> &dst) { return dec_->read_to_end(dst); }
+
+  private:
+    R inner_;
+    std::uint64_t remaining_;
+    std::unique_ptr<decode::Decoder<R>> dec_;
+};
+} // namespace vault
+
+} // namespace decode
+} // namespace huffman
+
+// --------------------------------------------------------------- adaptors
+
+// Cursor<Vec<u8>> as a Writer
+struct VecWriter {
+    std::vector<u8> buf;
+    std::size_t write(const u8 *p, std::size_t n)
+    {
+        buf.insert(buf.end(), p, p + n);
+        return n;
+    }
+    void flush() {}
+    const std::vector<u8> &get_ref() const { return buf; }
+};
+// Cursor<&[u8]> as a (seekable) Reader
+struct SliceReader {
+    const u8 *p = nullptr;
+    std::size_t n = 0, pos = 0;
+    SliceReader(const u8 *d, std::size_t len) : p(d), n(len) {}
+    explicit SliceReader(const std::vector<u8> &v) : p(v.data()), n(v.size()) {}
+    std::size_t read(u8 *dst, std::size_t len)
+    {
+        const std::size_t k = std::min(len, n - pos);
+        std::memcpy(dst, p + pos, k);
+        pos += k;
+        return k;
+    }
+    void rewind() { pos = 0; }
+};
+struct FileReader {
+    std::ifstream f;
+    explicit FileReader(const std::string &path) : f(path, std::ios::binary)
+    {
+        if (!f)
+            throw Panic(HF_ERR_BAD_ARG, "Failed to open source file");
+    }
+    std::size_t read(u8 *dst, std::size_t len)
+    {
+        f.read(reinterpret_cast<char *>(dst), (std::streamsize)len);
+        return (std::size_t)f.gcount();
+    }
+    void rewind()
+    {
+        f.clear();
+        f.seekg(0);
+    }
+};
+struct FileWriter {
+    std::ofstream f;
+    explicit FileWriter(const std::string &path) : f(path, std::ios::binary | std::ios::trunc)
+    {
+        if (!f)
+            throw Panic(HF_ERR_BAD_ARG, "Failed to create destination file");
+    }
+    std::size_t write(const u8 *p, std::size_t n)
+    {
+        f.write(reinterpret_cast<const char *>(p), (std::streamsize)n);
+        return n;
+    }
+    void flush() { f.flush(); }
+};
+
+// ------------------------------------------------------------- src/lib.rs
+
+// u64_to_bytes / bytes_to_u64 (src/lib.rs:82-102): big endian
+inline std::array<u8, 8> u64_to_bytes(std::uint64_t num)
+{
+    std::array<u8, 8> b{};
+    for (int i = 0; i < 8; ++i)
+        b[i] = (u8)(num >> (56 - 8 * i));
+    return b;
+}
+inline std::uint64_t bytes_to_u64(const u8 *bytes)
+{
+    std::uint64_t r = 0;
+    for (int i = 0; i < 8; ++i)
+        r += (std::uint64_t)bytes[i] << (56 - i * 8);
+    return r;
+}
+
+// Side file that carries the gap array of <destination>: "hfgap1\0\0",
+// u32 chunk_syms, u64 symbols, u64 n_chunks, u64 n_segs, chunk_bits, seg_off
+// (little endian).  The compressed file itself stays byte-identical to what
+// the reference writes.
+inline std::string gap_sidecar_path(const std::string &path) { return path + ".hfgap"; }
+inline void write_gap_sidecar(const std::string &path, const huffman::GapArray &g)
+{
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    const char tag[8] = {'h', 'f', 'g', 'a', 'p', '1', 0, 0};
+    const std::uint64_t nc = g.chunk_bits.size(), ns = g.seg_off.size();
+    f.write(tag, 8);
+    f.write(reinterpret_cast<const char *>(&g.chunk_syms), 4);
+    f.write(reinterpret_cast<const char *>(&g.symbols), 8);
+    f.write(reinterpret_cast<const char *>(&nc), 8);
+    f.write(reinterpret_cast<const char *>(&ns), 8);
+    f.write(reinterpret_cast<const char *>(g.chunk_bits.data()), (std::streamsize)(nc * 2));
+    f.write(reinterpret_cast<const char *>(g.seg_off.data()), (std::streamsize)(ns * 8));
+}
+inline bool read_gap_sidecar(const std::string &path, huffman::GapArray &g)
+{
+    std::ifstream f(path, std::ios::binary);
+    char tag[8];
+    std::uint64_t nc = 0, ns = 0;
+    if (!f || !f.read(tag, 8) || std::memcmp(tag, "hfgap1", 6) != 0)
+        return false;
+    f.read(reinterpret_cast<char *>(&g.chunk_syms), 4);
+    f.read(reinterpret_cast<char *>(&g.symbols), 8);
+    f.read(reinterpret_cast<char *>(&nc), 8);
+    f.read(reinterpret_cast<char *>(&ns), 8);
+    g.chunk_bits.resize(nc);
+    g.seg_off.resize(ns);
+    f.read(reinterpret_cast<char *>(g.chunk_bits.data()), (std::streamsize)(nc * 2));
+    f.read(reinterpret_cast<char *>(g.seg_off.data()), (std::streamsize)(ns * 8));
+    return (bool)f;
+}
+
+// stream_compress_with_header_information (src/lib.rs:31-80):
+// "pzhf" || u64-BE header length || bincode(Header) || bitstream.
+inline void stream_compress_with_header_information(const std::string &source,
+                                                    const std::string &destination)
+{
+    FileReader reader(source);
+    std::vector<u8> buffer(BUF);
+    auto h = huffman::Huffman::from_reader(reader);
+    huffman::encode::Encoder<FileWriter> writer(FileWriter(destination), h);
+    writer.track_write_value = false; // the return value of write() is unused here
+    auto hd = huffman::header::Header::from(writer);
+    std::ifstream sz(source, std::ios::binary | std::ios::ate);
+    hd.update_readbytes((std::uint64_t)sz.tellg()); // lib.rs:52-53
+    const auto header = hd.to_binary();
+    const auto header_length = u64_to_bytes(header.size());
+    writer.plain_write(writer.magic());
+    writer.plain_write(header_length.data(), 8);
+    writer.plain_write(header);
+    while (true) { // lib.rs:68-77
+        const std::size_t n = reader.read(buffer.data(), buffer.size());
+        if (n == 0)
+            break;
+        writer.write(buffer.data(), n);
+    }
+    writer.flush();
+    write_gap_sidecar(gap_sidecar_path(destination), writer.gap());
+}
+
+// stream_decompress_with_header_information (src/lib.rs:28-30) is
+// `unimplemented!()` in the reference; this is its natural completion through
+// Header::from_binary + Decoder::from_header.  Uses the gap side file when it
+// sits next to the source, else the sequential device walk.
+inline void stream_decompress_with_header_information(const std::string &source,
+                                                      const std::string &destination)
+{
+    FileReader reader(source);
+    u8 fixed[12];
+    if (reader.read(fixed, 12) != 12 || std::memcmp(fixed, "pzhf", 4) != 0)
+        throw Panic(HF_ERR_BAD_ARG, "not a pzhf file");
+    const std::uint64_t hlen = bytes_to_u64(fixed + 4);
+    std::vector<u8> hb(hlen);
+    if (reader.read(hb.data(), hlen) != hlen)
+        throw Panic(HF_ERR_BAD_ARG, "truncated header");
+    const auto hd = huffman::header::Header::from_binary(hb);
+    huffman::GapArray gap;
+    const bool have_gap = read_gap_sidecar(gap_sidecar_path(source), gap);
+    huffman::decode::Decoder<FileReader> dec(hd, std::move(reader), have_gap ? &gap : nullptr);
+    FileWriter out(destination);
+    std::vector<u8> all;
+    dec.read_to_end(all);
+    out.write(all.data(), all.size());
+    out.flush();
+}
+
+} // namespace rscompress_huffman
+#endif // HFGPU_HPP

@@ -1,0 +1,162 @@
+"""GPU tests of the host-buffer C entry points, of the C++ mirror of the
+reference API (include/hfgpu.hpp) and of the command line tool, against the
+CPU oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from huffman_amd import _lib, synth  # noqa: E402
+from huffman_amd._lib import u8p, u64p  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MIRROR = os.path.join(ROOT, "tests", "cpp", "test_mirror")
+CLI = os.path.join(ROOT, "huffman_amd", "bin", "hfgpu")
+u16p = C.POINTER(C.c_uint16)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (there is no CPU fallback)")
+    h = C.c_void_p()
+    assert _lib.lib().hf_ctx_create(0, C.byref(h)) == _lib.HF_OK
+    yield h
+    _lib.lib().hf_ctx_destroy(h)
+
+
+def make_model(ctx, codes, lens):
+    m = C.c_void_p()
+    rc = _lib.lib().hf_model_create(ctx, codes.ctypes.data_as(u64p), lens.ctypes.data_as(u64p),
+                                    C.byref(m))
+    assert rc == _lib.HF_OK, _lib.lib().hf_last_error(ctx)
+    return m
+
+
+@pytest.mark.parametrize("n", [0, 1, 4097, 300001])
+def test_histogram_host(ctx, orc, n):
+    data = synth.generate_host("zipf", n, seed=n + 5)
+    hist = np.zeros(256, dtype=np.uint64)
+    rc = _lib.lib().hf_histogram_host(ctx, data.ctypes.data_as(u8p), n, hist.ctypes.data_as(u64p))
+    assert rc == _lib.HF_OK
+    assert np.array_equal(hist, orc.histogram(data))
+
+
+@pytest.mark.parametrize("kind", ["zipf", "testfile", "geometric"])
+@pytest.mark.parametrize("n", [1, 65, 16384, 100003, (1 << 21) + 77])
+@pytest.mark.parametrize("gap", [True, False])
+def test_encode_decode_host(ctx, orc, kind, n, gap):
+    L = _lib.lib()
+    data = synth.generate_host(kind, n, seed=n)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    want, _ = orc.encode_slice(data, codes, lens)
+    model = make_model(ctx, codes, lens)
+    try:
+        cap = int(L.hf_encode_bound(model, n, 0))
+        out = np.zeros(cap, dtype=np.uint8)
+        nc, ns = C.c_uint64(), C.c_uint64()
+        assert L.hf_gap_layout(n, 64, C.byref(nc), C.byref(ns)) == _lib.HF_OK
+        cb = np.zeros(max(nc.value, 1), dtype=np.uint16)
+        so = np.zeros(max(ns.value, 1), dtype=np.uint64)
+        bits = C.c_uint64()
+        rc = L.hf_encode_host(ctx, model, data.ctypes.data_as(u8p), n, 0, out.ctypes.data_as(u8p),
+                              cap, 64, cb.ctypes.data_as(u16p) if gap else None,
+                              so.ctypes.data_as(u64p) if gap else None, C.byref(bits))
+        assert rc == _lib.HF_OK, L.hf_last_error(ctx)
+        nbytes = (bits.value + 7) // 8
+        assert nbytes == want.size and np.array_equal(out[:nbytes], want)
+        if not gap and n > 200000:
+            return  # the sequential walk is for small inputs
+        back = np.zeros(n, dtype=np.uint8)
+        rc = L.hf_decode_host(ctx, model, out.ctypes.data_as(u8p), nbytes, n, 64,
+                              cb.ctypes.data_as(u16p) if gap else None,
+                              so.ctypes.data_as(u64p) if gap else None, back.ctypes.data_as(u8p))
+        assert rc == _lib.HF_OK, L.hf_last_error(ctx)
+        assert np.array_equal(back, data)
+    finally:
+        L.hf_model_destroy(model)
+
+
+def test_encode_host_capacity_error(ctx, orc):
+    L = _lib.lib()
+    data = synth.generate_host("uniform", 50000, seed=2)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = make_model(ctx, codes, lens)
+    try:
+        out = np.zeros(1000, dtype=np.uint8)
+        bits = C.c_uint64()
+        rc = L.hf_encode_host(ctx, model, data.ctypes.data_as(u8p), data.size, 0,
+                              out.ctypes.data_as(u8p), out.size, 64, None, None, C.byref(bits))
+        assert rc == _lib.HF_ERR_CAPACITY
+    finally:
+        L.hf_model_destroy(model)
+
+
+def test_write_value_host_matches_oracle_automaton(ctx, orc):
+    L = _lib.lib()
+    data = synth.generate_host("testfile", 50000, seed=9)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    enc = orc.Encoder(codes, lens)
+    state = (C.c_uint64 * 3)(0, 64, 0)
+    for off in range(0, data.size, 4096):
+        piece = np.ascontiguousarray(data[off:off + 4096])
+        want = enc.write(piece)
+        ret = C.c_uint64()
+        rc = L.hf_encoder_write_value_host(ctx, piece.ctypes.data_as(u8p), piece.size,
+                                           codes.ctypes.data_as(u64p), lens.ctypes.data_as(u64p),
+                                           state, C.byref(ret))
+        assert rc == _lib.HF_OK
+        assert ret.value == want
+        assert state[2] == enc.writeout
+
+
+def test_cpp_mirror_replays_reference_tests():
+    assert os.path.exists(MIRROR), "build first: python huffman_amd/build.py"
+    r = subprocess.run([MIRROR], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    print(r.stderr)
+    assert r.returncode == 0 and "ALL OK" in r.stdout
+    assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 17
+
+
+def run_cli(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([CLI, *args], capture_output=True, text=True, timeout=300, env=e)
+
+
+@pytest.mark.parametrize("kind,n", [("testfile", 1 << 20), ("zipf", 3_000_001), ("uniform", 5)])
+def test_cli_container_matches_oracle_and_round_trips(tmp_path, orc, kind, n):
+    assert os.path.exists(CLI), "build first: python huffman_amd/build.py"
+    data = synth.generate_host(kind, n, seed=21)
+    src, dst, back = tmp_path / "in.bin", tmp_path / "out.pzhf", tmp_path / "back.bin"
+    src.write_bytes(data.tobytes())
+    r = run_cli(str(src), str(dst), "h", "c", env={"RUST_LOG": "info"})
+    assert r.returncode == 0, r.stderr
+    assert "Compressing file" in r.stderr
+    assert dst.read_bytes() == orc.compress_with_header(data)
+    assert os.path.exists(str(dst) + ".hfgap")
+    r = run_cli(str(dst), str(back), "h", "d")
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == data.tobytes()
+
+
+def test_cli_headerless_stream_and_argument_errors(tmp_path, orc):
+    data = synth.generate_host("testfile", 200001, seed=4)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.raw"
+    src.write_bytes(data.tobytes())
+    r = run_cli(str(src), str(dst), "x", "c")
+    assert r.returncode == 0, r.stderr
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    want, _ = orc.encode_slice(data, codes, lens)
+    assert dst.read_bytes() == want.tobytes()
+    assert run_cli(str(src)).returncode == 101
+    assert run_cli(str(src), str(dst), "h").returncode == 101
+    assert run_cli(str(src), str(dst), "h", "q").returncode == 101
+    assert run_cli(str(tmp_path / "missing"), str(dst), "h", "c").returncode == 101
