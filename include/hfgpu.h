@@ -44,8 +44,9 @@ typedef enum hf_status {
     HF_ERR_DECODE = 7,       /* bit window below the smallest key: the reference
                                 underflows and panics at src/huffman/decode/mod.rs:92,189 */
     HF_ERR_INTERNAL = 8,     /* device-side wait timed out */
-    HF_ERR_UNSUPPORTED = 9   /* code length 58..64 (the reference emits a damaged stream
-                                there) or sentinel above 57 */
+    HF_ERR_UNSUPPORTED = 9   /* code length 58..64 (the 64-bit buffer of the reference's
+                                put/cleanup automaton loses bits there and emits a damaged
+                                stream) or sentinel above 57 */
 } hf_status;
 
 typedef struct hf_ctx hf_ctx;     /* one GPU + stream + scratch */
