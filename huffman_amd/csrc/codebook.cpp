@@ -10,6 +10,7 @@
 #include "hfgpu_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -263,6 +264,50 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
         }
     }
     return HF_OK;
+}
+
+int pick_merge_width(const uint64_t lens[256], bool *speculative)
+{
+    double d[65] = {0}; // distribution of the code length of one symbol
+    double kraft = 0;
+    uint64_t maxlen = 0;
+    for (int s = 0; s < 256; ++s) {
+        if (lens[s] == 0 || lens[s] > 64)
+            continue;
+        const double w = std::ldexp(1.0, -(int)lens[s]);
+        d[lens[s]] += w;
+        kraft += w;
+        maxlen = std::max(maxlen, lens[s]);
+    }
+    *speculative = maxlen > 32;
+    if (kraft <= 0)
+        return 1;
+    for (double &x : d)
+        x /= kraft;
+    for (int g : {4, 2}) {
+        if (maxlen * g <= 32) {
+            *speculative = false;
+            return g;
+        }
+        // P(sum of g lengths > 32): convolve, lumping everything above 32
+        double c[34] = {0};
+        c[0] = 1.0;
+        for (int i = 0; i < g; ++i) {
+            double nc[34] = {0};
+            for (int a = 0; a <= 33; ++a)
+                for (int l = 1; l <= 64; ++l)
+                    if (c[a] != 0 && d[l] != 0)
+                        nc[std::min(a + l, 33)] += c[a] * d[l];
+            std::memcpy(c, nc, sizeof(c));
+        }
+        const double p_tile = 1.0 - std::pow(1.0 - c[33], 32.0 / g); // a lane's 32 symbols
+        const double p_wave = 1.0 - std::pow(1.0 - p_tile, 64.0);
+        if (p_wave <= 0.001) {
+            *speculative = true;
+            return g;
+        }
+    }
+    return 1;
 }
 
 } // namespace hf

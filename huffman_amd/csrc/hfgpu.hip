@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -173,8 +174,7 @@ constexpr int ENC_WINW = 5120;                  // words of stream image per pas
 constexpr int ENC_REPL = 4;                     // replicas of the packed table in LDS
 constexpr int ENC_BATCH = 4;                    // consecutive tiles per workgroup
 constexpr int ENC_MIN_WAVES = 6;                // waves per SIMD the register budget allows
-constexpr uint32_t ENC_PACKED_MAXLEN = 32;      // longest code a split {code, len} entry holds
-constexpr uint32_t ENC_LONG_FLAG = 1u << 31;    // len word of a longer code: flag | len
+constexpr uint32_t ENC_LONG_FLAG = 1u << 24;    // len word of a code above 32 bits: flag | len (four cannot wrap)
 
 constexpr unsigned long long DESC_AGG = 1ull << 62;  // batch total published
 constexpr unsigned long long DESC_INCL = 2ull << 62; // inclusive prefix published
@@ -322,15 +322,16 @@ struct EncSinkFlat {
     uint32_t *dump; // this lane's dump slot
     uint32_t nb;
     uint64_t acc;
+    bool alive; // once cleared, everything goes to the dump slot
     __device__ __forceinline__ EncSinkFlat(uint32_t *stg, uint32_t *dumps, uint32_t bitpos)
-        : ptr(stg + (bitpos >> 5)), dump(dumps + threadIdx.x), nb(bitpos & 31u), acc(0)
+        : ptr(stg + (bitpos >> 5)), dump(dumps + threadIdx.x), nb(bitpos & 31u), acc(0), alive(true)
     {
     }
     __device__ __forceinline__ void append(uint32_t code, uint32_t len) // len <= 32
     {
-        acc = (acc << len) | code;
+        acc = (acc << (len & 63u)) | code;
         nb += len;
-        const bool full = nb >= 32;
+        const bool full = nb >= 32 && alive;
         nb &= 31u;
         const uint32_t word = (uint32_t)(acc >> nb);
         __hip_atomic_fetch_or(full ? ptr : dump, word, __ATOMIC_RELAXED,
@@ -340,7 +341,8 @@ struct EncSinkFlat {
     __device__ __forceinline__ void finish()
     {
         const uint32_t word = nb ? (uint32_t)(acc << (32 - nb)) : 0u;
-        __hip_atomic_fetch_or(ptr, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or(alive ? ptr : dump, word, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
 
@@ -372,10 +374,13 @@ __device__ inline void enc_pack_thread_rolled(const EncParams &p, uint64_t sym0,
 
 // Fast form for a tile that fits one image pass.  The {code, len} entries are
 // looked up four at a time (64-bit LDS reads, no field extraction), the next
-// four while the current four are appended, so only eight of them are live;
-// G codes are merged per append (G * maxlen <= 32).  Codes longer than 32 bits
-// can only occur when G == 1: a group of four that holds one fetches its
-// codes from the 64-bit table (rare, wave-divergent).
+// four while the current four are merged, so only eight of them are live;
+// G codes are merged per append.  SPEC = a merged group can exceed 32 bits
+// (or the table holds codes longer than 32 bits, whose entries carry
+// ENC_LONG_FLAG in the length).  The loop has no branches: a lane that meets
+// such a group merely stops writing to the image -- what it wrote so far is
+// correct -- and the function returns false for it.  The caller then repeats
+// the lane's run with enc_pack_thread_rolled (ORing bits twice is harmless).
 // Dword q of tile t's symbols, picked out of the batch's registers by masking
 // (q is a compile-time constant at every use).  Written with AND/OR on
 // purpose: a chain of selects on t is recognised as raw[t][q] and turns the
@@ -390,9 +395,8 @@ __device__ __forceinline__ uint32_t enc_pick(const uint32_t (&raw)[ENC_BATCH][EN
     return v;
 }
 
-template <int G, bool FULL>
-__device__ __forceinline__ void enc_pack_thread(const EncParams &p,
-                                                const uint32_t (&raw)[ENC_BATCH][ENC_SPT / 4],
+template <int G, bool SPEC, bool FULL>
+__device__ __forceinline__ bool enc_pack_thread(const uint32_t (&raw)[ENC_BATCH][ENC_SPT / 4],
                                                 uint32_t t, uint32_t vcnt, const uint2 *s_tab2,
                                                 uint32_t *stg, uint32_t *dumps, uint32_t bitpos)
 {
@@ -413,40 +417,17 @@ __device__ __forceinline__ void enc_pack_thread(const EncParams &p,
     for (int q = 0; q < ENC_SPT / LG; ++q) {
         if (q + 1 < ENC_SPT / LG)
             fetch(nxt, q + 1);
-        bool has_long = false;
-        if (G == 1) {
-            uint32_t any = 0;
 #pragma unroll
-            for (int j = 0; j < LG; ++j)
-                any |= cur[j].y;
-            has_long = (any & ENC_LONG_FLAG) != 0;
-        }
-        if (G == 1 && __builtin_expect(has_long, 0)) {
-            for (int j = 0; j < LG; ++j) {
-                if (!FULL && (uint32_t)(LG * q + j) >= vcnt)
-                    break;
-                const uint32_t sym = (enc_pick(raw, t, q) >> (8 * j)) & 0xffu;
-                const uint64_t e = p.tab[sym];
-                const uint32_t len = (uint32_t)e & 63u;
-                const uint64_t code = e >> 6;
-                if (len > 32) {
-                    sink.append((uint32_t)(code >> 32), len - 32);
-                    sink.append((uint32_t)code, 32);
-                } else {
-                    sink.append((uint32_t)code, len);
-                }
+        for (int k = 0; k < LG; k += G) {
+            uint32_t code = cur[k].x, len = cur[k].y;
+#pragma unroll
+            for (int j = 1; j < G; ++j) {
+                code = (code << (cur[k + j].y & 31u)) | cur[k + j].x;
+                len += cur[k + j].y;
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < LG; k += G) {
-                uint32_t code = cur[k].x, len = cur[k].y;
-#pragma unroll
-                for (int j = 1; j < G; ++j) {
-                    code = (code << cur[k + j].y) | cur[k + j].x;
-                    len += cur[k + j].y;
-                }
-                sink.append(code, len);
-            }
+            if (SPEC)
+                sink.alive = sink.alive && len <= 32u;
+            sink.append(code, len);
         }
 #pragma unroll
         for (int j = 0; j < LG; ++j)
@@ -454,6 +435,7 @@ __device__ __forceinline__ void enc_pack_thread(const EncParams &p,
         __builtin_amdgcn_sched_barrier(0);
     }
     sink.finish();
+    return sink.alive;
 }
 
 // Bits of the symbols that follow the tile, up to `need` (< 32) of them, so
@@ -726,9 +708,10 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
 // at the end of the input, and unaligned inputs, with FULL = false so that the
 // hot instantiation carries no tail handling.  first_batch offsets the batch
 // index of such a follow-up launch.
-template <int G, bool CHAINED, bool FULL>
+template <int G, bool SPEC, bool FULL>
 __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(EncParams p)
 {
+    const bool CHAINED = p.desc != nullptr; // else: tile offsets come from the scan kernel
     __shared__ __align__(16) uint32_t stg[ENC_WINW];
     __shared__ uint2 s_tab[256 * ENC_REPL];
     __shared__ __align__(16) uint8_t s_len[256];
@@ -890,8 +873,12 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
             const uint32_t nwords = (uint32_t)(g1 - gbase);
             if (nwords <= ENC_WINW) {
                 // common case, straight-line: the whole tile fits one image pass
-                if (my_bits && !(p.debug & 2u))
-                    enc_pack_thread<G, FULL>(p, raw, t, vc, s_tab, stg, s_dump, s_lo + toff);
+                if (my_bits && !(p.debug & 2u)) {
+                    const bool done =
+                        enc_pack_thread<G, SPEC, FULL>(raw, t, vc, s_tab, stg, s_dump, s_lo + toff);
+                    if (SPEC && __builtin_expect(!done, 0)) // rare by the host's choice of G
+                        enc_pack_thread_rolled(p, base + t0, vc, stg, s_lo + toff, my_bits, 0);
+                }
                 enc_finish_pass(p, stg, s_ctl, s_tab, la, tile_end, E, gbase, g0, g1, endbit, need,
                                 nwords, 0);
             } else {
@@ -1204,8 +1191,33 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
     }
 }
 
-// Register-output form of the decode kernel for models whose table has no
-// escape entries (every code fits the first-level index) and 64-symbol chunks.
+// Escape entry `e` of the first level resolved from a 64-bit window whose
+// top `sentinel` bits are valid: walks the sub-tables, then falls back to the
+// predecessor search.  Returns a plain entry (len << 8 | sym); len 0 and
+// `bad` set when the window lies below the smallest key.
+__device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uint16_t *s_lut,
+                                             const DecParams &p, bool &bad)
+{
+    const uint32_t hi = (uint32_t)(win >> 32);
+    uint32_t used = p.w1;
+    while ((e & 0x8000u) && e < HF_LUT_INVALID) {
+        const uint32_t idx = (hi << used) >> (32 - HF_LUT_W2);
+        e = s_lut[(1u << p.w1) + ((e & 0x7fffu) << HF_LUT_W2) + idx];
+        used += HF_LUT_W2;
+    }
+    if (e < HF_LUT_INVALID)
+        return e;
+    if (e == HF_LUT_SEARCH) {
+        const int k = dec_predecessor(p.keys, p.m, win >> (64 - p.sentinel));
+        if (k >= 0)
+            return ((uint32_t)p.klens[k] << 8) | p.ksyms[k];
+    }
+    bad = true;
+    return 0;
+}
+
+// Register-output form of the decode kernel for 64-symbol chunks.  ESC = the
+// model's table has escape entries (codes longer than the first-level index).
 // A lane keeps its CS decoded bytes in CS/4 registers (the symbol loop is
 // fully unrolled), so the LDS image of the compressed words can be reused for
 // the output once every lane has finished reading it: a workgroup needs
@@ -1214,7 +1226,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
 // its dependent table lookups, i.e. by the number of chunks in flight.
 // Lanes whose chunk is ragged (end of the stream) and segments too dense for
 // the image take a rolled loop that stores bytes straight to global memory.
-template <int CS, int SPR>
+template <int CS, int K, bool ESC>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -1267,7 +1279,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     const bool fast = use_lds && cnt == (uint32_t)CS;
     uint32_t outw[CS / 4];
     bool bad = false;
-    if (fast) {
+    if (fast && K >= 8 && !ESC) {
+        // codes of at most 8 bits: a streaming reader that merges one word per
+        // 32 consumed bits touches LDS least (one word per four symbols)
         LdsWords src{img};
         BitReader<LdsWords> br(src, s_lo + excl);
         const uint32_t shift = 32 - p.w1;
@@ -1276,11 +1290,48 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             uint32_t pack = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (((4 * i + k) % SPR) == 0)
+                if (k == 0)
                     br.refill();
                 pack |= dec_symbol<LdsWords, false>(br, s_lut, shift, p, bad) << (8 * k);
             }
             outw[i] = pack;
+        }
+    } else if (fast) {
+        // No reader state besides the bit position: every K symbols the lane
+        // rebuilds a 64-bit window from the three image words at its position
+        // (K * sentinel <= 64, so the window never runs dry in between) -- no
+        // refill branches, and the table has no escape entries to test for.
+        uint32_t pos = s_lo + excl;
+        const uint32_t shift = 32 - p.w1;
+#pragma unroll
+        for (int i = 0; i < CS / 4; ++i)
+            outw[i] = 0;
+#pragma unroll
+        for (int g = 0; g < CS; g += K) {
+            const uint32_t *wp = img + (pos >> 5);
+            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const uint32_t sh = 32u - (pos & 31u); // 1..32
+            const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
+            const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
+            uint64_t win = ((uint64_t)hi << 32) | lo;
+            uint32_t used = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int j = g + k;
+                if (j < CS) {
+                    uint32_t e = s_lut[(uint32_t)(win >> 32) >> shift];
+                    if (ESC && __builtin_expect((e & 0x8000u) != 0, 0))
+                        e = dec_escape_window(win, e, s_lut, p, bad);
+                    const uint32_t len = e >> 8;
+                    win <<= len;
+                    used += len;
+                    // byte j % 4 of the output word takes the entry's low byte
+                    constexpr uint32_t keep = 0x03020100u;
+                    const uint32_t sel = (keep & ~(0xffu << (8 * (j & 3)))) | (0x04u << (8 * (j & 3)));
+                    outw[j >> 2] = __builtin_amdgcn_perm(e, outw[j >> 2], sel);
+                }
+            }
+            pos += used;
         }
     } else if (cnt) {
         // ragged chunk or oversized segment: bytes go straight to global memory
@@ -1428,6 +1479,8 @@ struct hf_model {
     uint32_t sentinel = 0;
     uint32_t w1 = 0;
     uint32_t maxlen = 0;
+    int enc_group = 1; // codes the encoder merges per append: 4, 2 or 1
+    bool enc_spec = false; // a merged group can exceed 32 bits
     bool has_encode = false;
     bool lut_escapes = false; // the decode table holds entries with the escape bit
 };
@@ -1704,11 +1757,13 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
     }
     if (maxlen == 0)
         return fail(ctx, HF_ERR_EMPTY, "model has no symbol with a code");
+    bool speculative = false;
+    const int group = hf::pick_merge_width(lens, &speculative);
     uint64_t enc[256];
     uint32_t enc2[512];
     for (int i = 0; i < 256; ++i) {
         enc[i] = (codes[i] << 6) | lens[i];
-        const bool fits = lens[i] <= ENC_PACKED_MAXLEN;
+        const bool fits = lens[i] <= 32;
         enc2[2 * i + 0] = fits ? (uint32_t)codes[i] : 0u;
         enc2[2 * i + 1] = fits ? (uint32_t)lens[i] : (ENC_LONG_FLAG | (uint32_t)lens[i]);
     }
@@ -1727,6 +1782,8 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
     mod->ctx = ctx;
     mod->maxlen = (uint32_t)maxlen;
     mod->has_encode = true;
+    mod->enc_group = group;
+    mod->enc_spec = speculative;
     rc = upload_model(ctx, mod, enc, enc2, lut, keys, syms, klens, m);
     if (rc != HF_OK) {
         delete mod;
@@ -1861,8 +1918,9 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     int rc = ensure_scratch(ctx, need);
     if (rc != HF_OK)
         return rc;
-    // codes merged per word-complete test: G * maxlen must fit 32 bits
-    const int g = model->maxlen <= 8 ? 4 : (model->maxlen <= 16 ? 2 : 1);
+    // codes merged per append, and whether the table flags codes too long for that
+    const int g = model->enc_group;
+    const bool flagged = model->enc_spec;
     const uint32_t n_batches = (n_tiles + ENC_BATCH - 1) / ENC_BATCH;
     // batches whose tiles are all complete run the lean instantiation; the
     // ragged last batch (and everything, if the input is unaligned) the general one
@@ -1888,7 +1946,7 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
         p.first_batch = lean ? 0u : n_lean;
         void (*kern)(EncParams) = nullptr;
 #define HF_PICK(G)                                                                           \
-    (chained ? (lean ? enc_pack_kernel<G, true, true> : enc_pack_kernel<G, true, false>)     \
+    (flagged ? (lean ? enc_pack_kernel<G, true, true> : enc_pack_kernel<G, true, false>)     \
              : (lean ? enc_pack_kernel<G, false, true> : enc_pack_kernel<G, false, false>))
         kern = g == 4 ? HF_PICK(4) : (g == 2 ? HF_PICK(2) : HF_PICK(1));
 #undef HF_PICK
@@ -2007,14 +2065,22 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     const int spr = model->sentinel <= 8 ? 4 : (model->sentinel <= 16 ? 2 : 1);
     void (*kern)(DecParams) = nullptr;
     size_t lds = 0;
-    if (!model->lut_escapes && chunk_syms == 64 && !(ctx->debug & 256)) {
+    if (chunk_syms == 64 && !(ctx->debug & 256)) {
         // register-output kernel: one LDS image serves as input, then as output
         const uint32_t in_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
         const uint32_t out_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
         p.istg_words = std::max(in_words, out_words);
         lds = lut_bytes + (size_t)(p.istg_words + 4) * 4;
-        kern = spr == 4 ? dec_kernel_reg<64, 4>
-                        : (spr == 2 ? dec_kernel_reg<64, 2> : dec_kernel_reg<64, 1>);
+        // symbols per window rebuild: K * sentinel <= 64
+        const uint32_t k = 64u / std::max<uint32_t>(model->sentinel, 1u);
+        if (model->lut_escapes)
+            kern = k >= 4 ? dec_kernel_reg<64, 4, true>
+                          : (k == 3 ? dec_kernel_reg<64, 3, true>
+                                    : (k == 2 ? dec_kernel_reg<64, 2, true>
+                                              : dec_kernel_reg<64, 1, true>));
+        else
+            kern = k >= 8 ? dec_kernel_reg<64, 8, false>
+                          : (k >= 6 ? dec_kernel_reg<64, 6, false> : dec_kernel_reg<64, 5, false>);
     } else {
         p.istg_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
         const uint32_t ostg_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);

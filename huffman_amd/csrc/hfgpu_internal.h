@@ -33,6 +33,14 @@ int build_codebook(const uint64_t *hist, uint64_t n, uint64_t codes[256], uint64
 uint64_t sentinel_of(const uint64_t lens[256]);
 int model_table(const uint64_t codes[256], const uint64_t lens[256], uint64_t keys[256],
                 uint8_t syms[256], uint8_t klens[256], uint64_t *m);
+// How many consecutive codes (4, 2 or 1) the encoder merges before one append
+// to its bit sink.  A merged group must fit 32 bits; a lane that meets a group
+// that does not has to redo its 32 symbols one code at a time through global
+// memory, and its wave waits for it.  Returns the widest width for which, with
+// symbols drawn with the probabilities 2^-len that the lengths imply, fewer
+// than one wave in a thousand has such a lane; `speculative` says whether a
+// group can overflow at all.
+int pick_merge_width(const uint64_t lens[256], bool *speculative);
 int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *klens, uint64_t m,
                      uint64_t sentinel, DecodeLut *lut);
 

@@ -175,6 +175,31 @@ def test_encode_long_codes(dev, orc):
     assert np.array_equal(out.cpu().numpy(), data)
 
 
+def test_encode_merged_groups_that_overflow(dev, orc):
+    # a model with code lengths 1..28: the encoder merges four codes per append
+    # on the expectation that a group fits 32 bits; data that the model calls
+    # improbable (runs of the rarest symbols) makes groups overflow, and those
+    # lanes must fall back without damaging their neighbours' bits
+    hist = np.zeros(256, dtype=np.uint64)
+    for k in range(29):
+        hist[k] = 1 << (28 - k)
+    codes, lens = orc.generate_extended_codewords(hist)
+    assert 16 < lens.max() <= 32
+    rng = np.random.default_rng(12)
+    data = rng.geometric(0.5, size=3 * 16384 + 333).clip(1, 29).astype(np.uint8) - 1
+    data[1000:1100] = 28                       # every group overflows here
+    data[16384 - 3: 16384 + 5] = 27            # across a tile edge
+    data[40000:40004] = [0, 28, 0, 28]         # a single overflowing group
+    data[-2:] = 28                             # at the very end
+    for mode in (0, 1):
+        model, enc = check_encode(dev, orc, data, codes, lens, mode=mode)
+    out = dev.decode(enc, model)
+    assert np.array_equal(out.cpu().numpy(), data)
+    worst = np.full(70000, 28, dtype=np.uint8)  # nothing but the longest code
+    model, enc = check_encode(dev, orc, worst, codes, lens)
+    assert np.array_equal(dev.decode(enc, model).cpu().numpy(), worst)
+
+
 def test_encode_symbols_without_code_add_no_bits(dev, orc):
     # absent symbols carry code 0 / length 0 (src/huffman/mod.rs:194-205); if
     # they occur in the data the reference appends nothing for them

@@ -6,11 +6,12 @@ sys.path.insert(0, ".")
 from huffman_amd import device as hd, synth
 
 n = 1 << 30
-data = synth.generate_device("zipf", n, seed=2024)
+kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
+data = synth.generate_device(kind, n, seed=2024)
 hist = hd.histogram(data)
 codes, lens = hd.build_codebook(hist)
 model = hd.DeviceModel(codes, lens)
-bufs = hd.EncodeBuffers(model, n, 128)
+bufs = hd.EncodeBuffers(model, n, 64)
 ctx = model.ctx
 def run(mode, dbg, reps=5):
     ctx.set_option("enc_mode", mode)
@@ -25,7 +26,8 @@ def run(mode, dbg, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 names = {0: "full", 4: "full, blockIdx as ticket", 9: "stageA only (no lookback)", 13: "stageA only, blockIdx ticket",
-         1: "stageA+lookback", 5: "stageA+lookback, blockIdx ticket"}
+         1: "stageA+lookback", 5: "stageA+lookback, blockIdx ticket", 2: "no pack (finish only)",
+         8: "full minus lookback"}
 for mode in (1,):
     for dbg, name in names.items():
         print(f"mode {mode} debug {dbg:2d} {name:28s} {run(mode, dbg):.3f} ms", flush=True)
