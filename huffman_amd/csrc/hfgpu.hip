@@ -108,11 +108,23 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const uint8_t *__res
     const uint4 *vin = reinterpret_cast<const uint4 *>(in + head);
     const uint64_t stride = (uint64_t)gridDim.x * HIST_THREADS;
     uint64_t v = (uint64_t)blockIdx.x * HIST_THREADS + threadIdx.x;
-    for (; v + (HIST_UNROLL - 1) * stride < nvec; v += HIST_UNROLL * stride) {
-        uint4 x[HIST_UNROLL];
+    // software pipeline: the next HIST_UNROLL vectors are requested before the
+    // current ones are counted, so loads stay in flight during the LDS phase
+    uint4 x[HIST_UNROLL], y[HIST_UNROLL];
+    bool have = v + (HIST_UNROLL - 1) * stride < nvec;
+    if (have) {
 #pragma unroll
         for (int u = 0; u < HIST_UNROLL; ++u)
             x[u] = vin[v + u * stride];
+    }
+    while (have) {
+        const uint64_t vn = v + HIST_UNROLL * stride;
+        const bool more = vn + (HIST_UNROLL - 1) * stride < nvec;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < HIST_UNROLL; ++u)
+                y[u] = vin[vn + u * stride];
+        }
 #pragma unroll
         for (int u = 0; u < HIST_UNROLL; ++u) {
             hist_add4(col, x[u].x);
@@ -120,6 +132,11 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const uint8_t *__res
             hist_add4(col, x[u].z);
             hist_add4(col, x[u].w);
         }
+#pragma unroll
+        for (int u = 0; u < HIST_UNROLL; ++u)
+            x[u] = y[u];
+        v = vn;
+        have = more;
     }
     for (; v < nvec; v += stride) {
         const uint4 x = vin[v];
@@ -722,11 +739,12 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
     __shared__ uint32_t s_ctl[2];
     __shared__ uint32_t s_batch;
 
-    enc_stage_table(p, s_tab, s_len);
+    // the ticket first: its round trip overlaps with the staging of the tables
     if (CHAINED) {
         if (threadIdx.x == 0)
             s_batch = p.first_batch + ((p.debug & 4u) ? blockIdx.x : atomicAdd(p.ticket, 1u));
     }
+    enc_stage_table(p, s_tab, s_len);
     for (uint32_t i = threadIdx.x; i < ENC_WINW / 4; i += ENC_THREADS)
         reinterpret_cast<uint4 *>(stg)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
