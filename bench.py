@@ -188,12 +188,14 @@ def main():
     dom = max(("encode", "decode"), key=lambda k: kernels[k]["ms"])
     roofline = {
         "bound": "hbm",
-        "kernel": {"encode": "enc_pack_kernel", "decode": "dec_kernel"}[dom],
+        "kernel": {"encode": "enc_pack_kernel",
+                   "decode": "dec_kernel_reg" if cs == 64 else "dec_kernel"}[dom],
         "achieved": round(kernels[dom]["GBps"], 1),
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBPS, 4),
-        "traffic": None,
+        "traffic": pmc_traffic(args.kind, n, cs, dom),
+        "alg_bytes": kernels[dom]["alg_bytes"],
     }
 
     result = {
@@ -237,6 +239,20 @@ def main():
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("round trip mismatch")
+
+
+def pmc_traffic(kind: str, n: int, cs: int, kernel: str):
+    """HBM bytes per launch of `kernel` from the PMC counters (FETCH_SIZE doubled
+    as gfx950 needs, plus WRITE_SIZE), collected in separate rocprofv3 --pmc
+    passes on this workload and recorded in huffman_amd/pmc_traffic.json by
+    tools/make_traffic.py; None when this workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "huffman_amd", "pmc_traffic.json")) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    entry = table.get(f"{kind}:{n}:{cs}")
+    return entry.get(kernel) if entry else None
 
 
 def cpu_baseline(data: torch.Tensor, sample_mib: int) -> dict:

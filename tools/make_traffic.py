@@ -1,0 +1,27 @@
+"""Records the HBM traffic per kernel launch measured by tools/pmc.sh (summary
+JSON of tools/pmc_summary.py) in huffman_amd/pmc_traffic.json, keyed by the
+workload, so that bench.py can report it next to the algorithmic bytes.
+usage: python tools/make_traffic.py <pmc_summary.json> <kind> <bytes> <chunk_syms> <source label>"""
+import json
+import os
+import sys
+
+summary, kind, nbytes, cs, label = sys.argv[1:6]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = os.path.join(root, "huffman_amd", "pmc_traffic.json")
+try:
+    table = json.load(open(path))
+except (OSError, ValueError):
+    table = {}
+entry = {"source": label}
+for name, v in json.load(open(summary)).items():
+    if "hbm_read_bytes_corrected" not in v or "hbm_write_bytes" not in v:
+        continue
+    key = "histogram" if name.startswith("hist") else ("encode" if name.startswith("enc_pack") else
+                                                       ("decode" if name.startswith("dec_kernel") else None))
+    if key:
+        entry[key] = int(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
+        entry[key + "_kernel"] = name
+table[f"{kind}:{nbytes}:{cs}"] = entry
+json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+print(json.dumps(entry))

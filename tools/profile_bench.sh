@@ -10,4 +10,12 @@ f=$(find gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1)
 cat gpurun_out/${tag}_kernel_stats.csv
 cat gpurun_out/${tag}_bench_under_rocprof.json
 ./tools/pmc.sh gpurun_out/${tag}_pmc zipf 1024 64 > gpurun_out/${tag}_pmc_summary.json || exit 1
-cat gpurun_out/${tag}_pmc_summary.json
+./tools/pmc.sh gpurun_out/${tag}_pmc_geo geometric 1024 64 > gpurun_out/${tag}_pmc_geometric_summary.json || exit 1
+./tools/pmc.sh gpurun_out/${tag}_pmc_uni uniform 1024 64 > gpurun_out/${tag}_pmc_uniform_summary.json || exit 1
+python3 -c "
+import json
+for f in ['', '_geometric', '_uniform']:
+    d = json.load(open('gpurun_out/${tag}_pmc%s_summary.json' % f))
+    for k, v in d.items():
+        print(f or '_zipf', k, 'read %.3f GB write %.3f GB' % (v.get('hbm_read_bytes_corrected', 0) / 1e9, v.get('hbm_write_bytes', 0) / 1e9))
+"
