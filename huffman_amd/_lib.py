@@ -67,6 +67,8 @@ SIGNATURES = {
                             C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hf_decode_serial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                    C.c_uint64, C.c_void_p]),
+    "hf_build_gap_array": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                     C.c_uint32, C.c_void_p, C.c_void_p]),
     "hf_histogram_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
     "hf_encode_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                  C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, u64p]),

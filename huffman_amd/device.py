@@ -257,6 +257,20 @@ def decode_serial(data: torch.Tensor, in_bytes: int, model: DeviceModel, n_out: 
     return out
 
 
+def build_gap_array(data: torch.Tensor, in_bytes: int, model: DeviceModel, n_out: int,
+                    chunk_syms: int = DEFAULT_CHUNK_SYMS) -> tuple[torch.Tensor, torch.Tensor]:
+    """Gap array (chunk_bits, seg_off) of a stream that came without one; the
+    pair then drives decode_async / decode."""
+    ctx = model.ctx
+    ctx.bind_stream()
+    nc, ns = gap_layout(n_out, chunk_syms)
+    chunk_bits = torch.empty(max(nc, 1), dtype=torch.int16, device=ctx.device)
+    seg_off = torch.empty(max(ns, 1), dtype=torch.int64, device=ctx.device)
+    ctx.check(lib().hf_build_gap_array(ctx.handle, model.handle, data.data_ptr(), in_bytes, n_out,
+                                       chunk_syms, chunk_bits.data_ptr(), seg_off.data_ptr()))
+    return chunk_bits, seg_off
+
+
 def encoder_write_value(t: torch.Tensor, codes, lens, state) -> tuple[int, list[int]]:
     """Return value of one Encoder::write call and the updated
     {buffer, remaining_bits, writeout} state (src/huffman/encode.rs:91-116)."""

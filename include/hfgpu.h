@@ -201,6 +201,21 @@ HF_API int hf_decode_serial(hf_ctx *ctx, const hf_model *model, const uint8_t *d
                             uint64_t in_bytes, uint64_t bit_base, uint64_t n_out,
                             uint8_t *d_out);
 
+/* Gap array of a stream that came without one, e.g. a file the reference wrote
+ * (src/lib.rs:31-80 stores no side metadata; its decoders, src/huffman/decode/
+ * mod.rs:70-231, walk the stream sequentially).  The device decodes
+ * sub-sequences of the stream speculatively in parallel and iterates until
+ * every one starts where its predecessor ends -- the sequential decode's own
+ * code boundaries, for any model -- then records the bit position of every
+ * chunk_syms-th symbol.  Synchronous.  d_chunk_bits / d_seg_off are sized by
+ * hf_gap_layout(n_out, chunk_syms) and then drive hf_decode.  HF_ERR_DECODE
+ * when the stream holds fewer than n_out symbols (hf_decode_serial continues
+ * such a stream with zero bits as the reference does) or a bit window lies
+ * below the smallest key. */
+HF_API int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in,
+                              uint64_t in_bytes, uint64_t n_out, uint32_t chunk_syms,
+                              uint16_t *d_chunk_bits, uint64_t *d_seg_off);
+
 /* ------------------------------------------------------- host-buffer forms
  *
  * The same operations for callers whose data lives in host memory (what a

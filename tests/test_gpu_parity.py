@@ -395,3 +395,91 @@ def test_large_roundtrip_properties(dev, kind):
     assert torch.equal(enc0.chunk_bits, enc.chunk_bits) and torch.equal(enc0.seg_off, enc.seg_off)
     out = dev.decode(enc, model)
     assert torch.equal(out, t)
+
+
+# ------------------------------------------- gap array rebuilt from the stream
+
+@pytest.mark.parametrize("kind", ["zipf", "testfile", "geometric", "uniform"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4096, 16385, 100003, (1 << 21) + 77])
+def test_build_gap_array_matches_the_encoders(dev, orc, kind, n):
+    data = synth.generate_host(kind, n, seed=n + 3)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    cb, so = dev.build_gap_array(enc.data, enc.nbytes, model, n)
+    nc, ns = dev.gap_layout(n, 64)
+    assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
+    assert torch.equal(so[:ns], enc.seg_off[:ns])
+    bare = dev.Encoded(enc.data, enc.total_bits, 0, n, 64, cb, so)
+    assert np.array_equal(dev.decode(bare, model).cpu().numpy(), data)
+
+
+@pytest.mark.parametrize("chunk_syms", [128, 256])
+def test_build_gap_array_chunk_sizes(dev, orc, chunk_syms):
+    data = synth.generate_host("zipf", 300001, seed=5)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model, chunk_syms=chunk_syms)
+    cb, so = dev.build_gap_array(enc.data, enc.nbytes, model, data.size, chunk_syms)
+    nc, ns = dev.gap_layout(data.size, chunk_syms)
+    assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
+    assert torch.equal(so[:ns], enc.seg_off[:ns])
+
+
+def test_build_gap_array_model_that_is_not_prefix_free(dev, orc):
+    # overlapping codes, as in decode_numbers (src/huffman/decode/mod.rs:240-258),
+    # but with a key 0 so that every bit string decodes: '0', '1', '11', '101'.
+    # The code boundaries are those of the sequential predecessor-search decode,
+    # not those of the symbols that were encoded.
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    for sym, (c, l) in enumerate([(0b0, 1), (0b1, 1), (0b11, 2), (0b101, 3)]):
+        codes[sym], lens[sym] = c, l
+    rng = np.random.default_rng(4)
+    data = rng.integers(0, 4, size=90000, dtype=np.uint8)
+    stream, _ = orc.encode_slice(data, codes, lens)
+    n_out = data.size // 3          # cannot run past the end of the stream
+    # the reference's slice decoder only honours the count in its drain loop
+    # (src/huffman/decode/mod.rs:187-229): it returns every symbol of the stream
+    want = orc.decode_read(stream, codes, lens, n_out)[:n_out]
+    assert not np.array_equal(want, data[:n_out])   # the model really is ambiguous
+    model = dev.DeviceModel(codes, lens)
+    t = to_gpu(np.concatenate([stream, np.zeros(16, dtype=np.uint8)]))
+    cb, so = dev.build_gap_array(t, stream.size, model, n_out)
+    bare = dev.Encoded(t, stream.size * 8, 0, n_out, 64, cb, so)
+    assert np.array_equal(dev.decode(bare, model).cpu().numpy(), want)
+    assert np.array_equal(dev.decode_serial(t, stream.size, model, n_out).cpu().numpy(), want)
+
+
+def test_build_gap_array_long_codes(dev, orc):
+    codes, lens = fib_model(orc, 40)
+    rng = np.random.default_rng(18)
+    data = rng.integers(0, 40, size=70001, dtype=np.uint8)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    cb, so = dev.build_gap_array(enc.data, enc.nbytes, model, data.size)
+    nc, ns = dev.gap_layout(data.size, 64)
+    assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
+    assert torch.equal(so[:ns], enc.seg_off[:ns])
+
+
+def test_build_gap_array_stream_too_short(dev, orc):
+    data = synth.generate_host("zipf", 50000, seed=1)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    with pytest.raises(dev.HfError) as ei:
+        dev.build_gap_array(enc.data, enc.nbytes // 2, model, data.size)
+    assert ei.value.status == dev._lib.HF_ERR_DECODE
+
+
+def test_build_gap_array_256mib_property(dev):
+    n = 1 << 28
+    data = synth.generate_device("zipf", n, seed=77)
+    codes, lens = dev.build_codebook(dev.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(data, model)
+    cb, so = dev.build_gap_array(enc.data, enc.nbytes, model, n)
+    nc, ns = dev.gap_layout(n, 64)
+    assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
+    assert torch.equal(so[:ns], enc.seg_off[:ns])
