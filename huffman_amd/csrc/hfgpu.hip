@@ -1467,6 +1467,7 @@ struct GapParams {
     uint32_t *start32;   // [n_chunks + 1] low 32 bits of the chunk start bits
     uint64_t n_chunks;
     uint32_t first;      // first launch: no earlier results to reuse
+    uint32_t per_window; // symbols decoded per 64-bit window: per_window * sentinel <= 64
     uint16_t *chunk_bits;
     uint64_t *seg_off;
 };
@@ -1482,24 +1483,41 @@ __device__ __forceinline__ uint32_t gap_entry(uint64_t win, const uint16_t *s_lu
     return e;
 }
 
+// 64-bit window at image bit `rel` (three words, see GapWords).
+__device__ __forceinline__ uint64_t gap_window(const GapWords &src, uint32_t rel)
+{
+    const uint32_t w = rel >> 5;
+    const uint32_t w0 = src(w), w1 = src(w + 1), w2 = src(w + 2);
+    const uint32_t sh = 32u - (rel & 31u); // 1..32
+    const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
+    const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // Decodes from bit `start` of sub-sequence `i` to its end; returns the exit
-// offset and the number of codes.  Src indexes 32-bit words relative to the
-// first word of the workgroup's range.
-template <typename Src>
-__device__ __forceinline__ void gap_walk(const Src &src, const GapParams &g, uint64_t i,
+// offset and the number of codes.  The window is rebuilt every `per_window`
+// symbols (per_window * sentinel <= 64).
+__device__ __forceinline__ void gap_walk(const GapWords &src, const GapParams &g, uint64_t i,
                                          uint32_t start, const uint16_t *s_lut, uint32_t &exit_off,
                                          uint32_t &count)
 {
     const uint64_t left = g.total_bits - i * GAP_SUB_BITS; // bits from the sub-sequence's begin
     const uint32_t end = left < GAP_SUB_BITS ? (uint32_t)left : GAP_SUB_BITS;
     const uint32_t rel0 = (uint32_t)(i % GAP_THREADS) * GAP_SUB_BITS;
+    const uint32_t per_window = g.per_window;
     uint32_t pos = start, c = 0;
     bool bad = false;
     while (pos < end) {
-        const uint32_t e = gap_entry(dec_peek64(src, rel0 + pos), s_lut, g.d, bad);
-        const uint32_t len = e >> 8;
-        pos += len ? len : 1u; // a wrong guess may land anywhere: keep moving
-        ++c;
+        uint64_t win = gap_window(src, rel0 + pos);
+#pragma unroll 1
+        for (uint32_t k = 0; k < per_window && pos < end; ++k) {
+            const uint32_t e = gap_entry(win, s_lut, g.d, bad);
+            uint32_t len = e >> 8;
+            len = len ? len : 1u; // a wrong guess may land anywhere: keep moving
+            win <<= len;
+            pos += len;
+            ++c;
+        }
     }
     exit_off = pos >= GAP_SUB_BITS ? pos - GAP_SUB_BITS : 0u;
     count = c;
@@ -1664,21 +1682,28 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_emit_kernel(GapParams g)
     uint32_t until = (uint32_t)(s % cs ? cs - s % cs : 0); // symbols until the next chunk opens
     bool bad = false;
     GapWords src{img};
+    const uint32_t per_window = g.per_window;
     while (pos < end && s < g.d.n_out) {
-        if (until == 0) {
-            const uint64_t c = s / cs;
-            g.start32[c] = (uint32_t)(bit0 + pos);
-            if ((c % HF_SEG_CHUNKS) == 0)
-                g.seg_off[c / HF_SEG_CHUNKS] = bit0 + pos;
-            until = cs;
+        uint64_t win = gap_window(src, rel0 + pos);
+#pragma unroll 1
+        for (uint32_t k = 0; k < per_window && pos < end && s < g.d.n_out; ++k) {
+            if (until == 0) {
+                const uint64_t c = s / cs;
+                g.start32[c] = (uint32_t)(bit0 + pos);
+                if ((c % HF_SEG_CHUNKS) == 0)
+                    g.seg_off[c / HF_SEG_CHUNKS] = bit0 + pos;
+                until = cs;
+            }
+            const uint32_t e = gap_entry(win, s_lut, g.d, bad);
+            uint32_t len = e >> 8;
+            len = len ? len : 1u;
+            win <<= len;
+            pos += len;
+            ++s;
+            --until;
+            if (s == g.d.n_out)
+                g.start32[g.n_chunks] = (uint32_t)(bit0 + pos); // end of the last chunk
         }
-        const uint32_t e = gap_entry(dec_peek64(src, rel0 + pos), s_lut, g.d, bad);
-        const uint32_t len = e >> 8;
-        pos += len ? len : 1u;
-        ++s;
-        --until;
-        if (s == g.d.n_out)
-            g.start32[g.n_chunks] = (uint32_t)(bit0 + pos); // end of the last chunk
     }
     if (bad)
         atomicOr((unsigned long long *)&g.d.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
@@ -2448,6 +2473,7 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
     if (in_bytes == 0 || in_bytes >= (1ull << 58))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: empty or oversized stream");
     g.d.chunk_syms = chunk_syms;
+    g.per_window = std::max(1u, 64u / std::max(1u, g.d.sentinel));
     g.total_bits = in_bytes * 8;
     g.n_sub = (g.total_bits + GAP_SUB_BITS - 1) / GAP_SUB_BITS;
     g.n_wg = (g.n_sub + GAP_THREADS - 1) / GAP_THREADS;
