@@ -10,11 +10,12 @@ timed region) are reported alongside.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 N=1: 1 GiB Zipf(s=1.1) stream.  N>1 (launched by torch.distributed.run, one
-rank per GPU): every rank owns a contiguous 2 GiB shard of one logical stream
-(N=8 -> the 16 GiB configuration); the 256-bin histograms are all-reduced over
-RCCL, every rank builds the same codebook, the shards' bit lengths are
-all-gathered and scanned so that each shard is encoded at its own bit phase of
-the global stream.  The compressed shards stay where they are unless --gather.
+rank per GPU): every rank owns a contiguous 1 GiB shard of one logical stream
+(weak scaling; --gib 2 at N=8 is the 16 GiB configuration); the 256-bin
+histograms are all-gathered over RCCL, every rank sums them and builds the same
+codebook, and the exclusive scan of the shards' bit lengths (histogram row x
+code lengths) places each shard at its own bit phase of the global stream.
+The compressed shards stay where they are unless --gather.
 """
 from __future__ import annotations
 
@@ -32,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 from huffman_amd import device as hd  # noqa: E402
 from huffman_amd import synth  # noqa: E402
-from huffman_amd.dist import ShardPlan, plan_shards  # noqa: E402
+from huffman_amd.dist import gather_histograms, plan_from_histograms  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform", "geometric", "testfile"])
-    ap.add_argument("--gib", type=float, default=None, help="GiB per GPU (default 1, or 2 when N>1)")
+    ap.add_argument("--gib", type=float, default=None, help="GiB per GPU (default 1)")
     ap.add_argument("--chunk-syms", type=int, default=hd.DEFAULT_CHUNK_SYMS)
     ap.add_argument("--enc-mode", type=int, default=1)
     ap.add_argument("--gather", action="store_true", help="also gather the shards to rank 0")
@@ -83,12 +84,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # HF_BENCH_FORCE_DIST=1 runs the collectives with a single rank too (a
+    # rehearsal of the multi-GPU code path on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("HF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist  # noqa: F811
 
         dist.init_process_group("nccl", device_id=dev)
 
-    gib = args.gib if args.gib is not None else (1.0 if world == 1 else 2.0)
+    gib = args.gib if args.gib is not None else 1.0
     n = int(gib * (1 << 30))
     data = synth.generate_device(args.kind, n, seed=args.seed + rank, device=dev)
     ctx = hd.Context.get(dev)
@@ -104,25 +108,27 @@ def main():
 
     def step(timed: bool):
         nonlocal bufs
-        # pass 1: histogram (+ all-reduce of 2 KiB over RCCL)
+        # pass 1: histogram
         if timed:
             st_hist.start()
         hd.histogram_async(data, d_hist)
         if timed:
             st_hist.stop()
-        local_hist = d_hist.clone() if world > 1 else d_hist
-        if world > 1:
-            dist.all_reduce(d_hist, op=dist.ReduceOp.SUM)
-        hist = d_hist.cpu().numpy().astype(np.uint64)
-        # host: codebook, then device tables
-        codes, lens = hd.build_codebook(hist)
-        model = hd.DeviceModel(codes, lens, device=dev)
-        # cross-GPU exclusive scan of the shards' bit lengths
+        # host: codebook, then device tables.  With several ranks one all-gather
+        # of the 2 KiB histograms merges them and, times the code lengths, gives
+        # every shard's bit length: the cross-GPU exclusive scan is then local
         lead = 0
         plan = None
-        if world > 1:
-            my_bits = int((local_hist.cpu().numpy().astype(np.uint64) * lens).sum())
-            plan = plan_shards(my_bits, dist, dev)
+        if use_dist:
+            hists = gather_histograms(d_hist, dist)
+            hist = hists.sum(axis=0).astype(np.uint64)
+        else:
+            hist = d_hist.cpu().numpy().astype(np.uint64)
+        codes, lens = hd.build_codebook(hist)
+        model = hd.DeviceModel(codes, lens, device=dev)
+        if use_dist:
+            plan = plan_from_histograms(hists, lens, rank)
+            my_bits = plan.bits[rank]
             lead = plan.lead_bits
         if bufs is None:
             cap = hd.DeviceModel.encode_bound(model, n, 7)
@@ -134,9 +140,9 @@ def main():
         if timed:
             st_enc.stop()
         # the stream length is needed on the host (and is known from the histogram)
-        total_bits = int((hist * lens).sum()) if world == 1 else my_bits
+        total_bits = my_bits if use_dist else int((hist * lens).sum())
         nbytes = (lead + total_bits + 7) // 8
-        if args.gather and world > 1:
+        if args.gather and use_dist:
             plan.gather(bufs.data[:nbytes], dist)
         # decode from the gap array
         if timed:
@@ -148,7 +154,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -160,7 +166,7 @@ def main():
         step(True)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -168,7 +174,7 @@ def main():
     # correctness of what was timed: flags clear, round trip exact
     flags = int(bufs.result[1].item()) | int(dres[1].item())
     ok = flags == 0 and int(bufs.result[0].item()) == state["total_bits"] and torch.equal(out, data)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = bool(t.item())
@@ -234,7 +240,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(data, args.cpu_sample_mib)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:

@@ -9,6 +9,8 @@ place the shards in the global stream; an optional bulk one moves them:
      = the cross-GPU scan: shard r starts at bit start_bit[r] of the stream and
      is encoded with lead_bits = start_bit[r] % 8 leading zero bits, so shards
      concatenate bytewise and only the boundary byte needs an OR;
+     (gather_histograms + plan_from_histograms fold 1 and 2 into a single
+     all-gather of the histograms: one collective and one host sync per stream);
   3. (optional) the shards are sent to rank 0 and merged into one stream.
      Root-inbound xGMI is 7 links x ~153 GB/s, below one GPU's encode rate, so
      keeping the stream sharded (this plan is its descriptor) is the default.
@@ -102,6 +104,32 @@ def plan_shards(my_bits: int, dist, device) -> ShardPlan:
         start.append(acc)
         acc += b
     return ShardPlan(rank, world, bits, start)
+
+
+def gather_histograms(local_hist: torch.Tensor, dist):
+    """All ranks' 256-bin histograms on every rank's host, shape [world, 256]:
+    one all-gather of 2 KiB per rank and one device-to-host copy carry both
+    exchanges of the plan -- the sum over ranks is the global histogram, and
+    since every rank derives the same codebook from it, row r times the code
+    lengths is shard r's bit length (plan_from_histograms)."""
+    world = dist.get_world_size()
+    every = torch.empty(world * 256, dtype=local_hist.dtype, device=local_hist.device)
+    dist.all_gather_into_tensor(every, local_hist.contiguous())
+    return every.view(world, 256).cpu().numpy()
+
+
+def plan_from_histograms(hists, lens, rank: int) -> ShardPlan:
+    """The cross-rank exclusive scan of the shards' bit lengths, computed
+    identically on every rank from the gathered histograms."""
+    import numpy as np
+
+    bits = [int(b) for b in (np.asarray(hists, dtype=np.uint64)
+                             * np.asarray(lens, dtype=np.uint64)[None, :]).sum(axis=1)]
+    start, acc = [], 0
+    for b in bits:
+        start.append(acc)
+        acc += b
+    return ShardPlan(rank, len(bits), bits, start)
 
 
 def allreduce_histogram(hist: torch.Tensor, dist) -> torch.Tensor:

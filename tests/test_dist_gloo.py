@@ -11,7 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from huffman_amd import synth
-from huffman_amd.dist import allreduce_histogram, plan_shards
+from huffman_amd.dist import (allreduce_histogram, gather_histograms, plan_from_histograms,
+                              plan_shards)
 
 
 def free_port():
@@ -45,6 +46,12 @@ def worker(rank, world, port, cuts, q):
         codes, lens = orc.generate_extended_codewords(hist.numpy().astype(np.uint64))
         my_bits = int(lens[shard].sum())
         plan = plan_shards(my_bits, dist, torch.device("cpu"))
+        # the single-collective form used by bench.py gives the same plan
+        hists = gather_histograms(torch.from_numpy(orc.histogram(shard).astype(np.int64)), dist)
+        assert np.array_equal(hists.sum(axis=0).astype(np.uint64), orc.histogram(data))
+        plan2 = plan_from_histograms(hists, lens, rank)
+        assert plan2.bits == plan.bits and plan2.start_bit == plan.start_bit
+        assert plan2.lead_bits == plan.lead_bits
         local, nbits = shifted_stream(orc, shard, codes, lens, plan.lead_bits)
         assert nbits == my_bits
         f, l = plan.byte_range(rank)
