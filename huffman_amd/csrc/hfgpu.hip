@@ -158,37 +158,35 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const uint8_t *__res
 
 // ------------------------------------------------------------------- encode
 //
-// A tile is 16384 consecutive symbols; a 512-thread workgroup encodes one
-// tile, each thread a run of 32 consecutive symbols (two 16-byte loads).
-//   1. every symbol is looked up ONCE in an LDS table of packed 32-bit
-//      entries (code << 6 | len; four replicas, a lane uses replica lane%4, so
-//      random symbols spread over all banks); the 32 entries stay in
-//      registers.  Their length fields give the thread's bit total; a
-//      workgroup scan turns the totals into bit offsets inside the tile (and
-//      into the chunk lengths of the gap array);
-//   2. start bit of the tile in the stream: either read from a scanned array
+// A tile is 16384 consecutive symbols: 512 threads x a run of 32 consecutive
+// symbols (two 16-byte loads) each.  A workgroup handles a batch of four tiles.
+//   1. the symbols stay in registers; a byte table of code lengths in LDS
+//      gives every thread's bit total, and a workgroup scan turns the totals
+//      into bit offsets inside the tile (and into the chunk lengths of the
+//      gap array);
+//   2. start bit of the batch in the stream: either read from a scanned array
 //      (three-kernel mode) or obtained inside the same launch by a chained
 //      scan with decoupled look-back over 8-byte {status,value} descriptors;
-//   3. every thread streams its codes MSB-first through a 64-bit accumulator
-//      and ORs finished 32-bit words into an LDS image of the tile's part of
-//      the stream (the image is aligned to 16-byte units of the stream); G
-//      neighbouring codes are merged first when G * maxlen <= 32, so the
-//      word-complete test runs once per G symbols;
+//   3. every thread looks its symbols up in an LDS table of {code, len} pairs
+//      (four replicas, a lane uses replica lane % 4), merges G neighbouring
+//      codes, streams them MSB-first through a 64-bit accumulator and ORs
+//      finished 32-bit words into an LDS image of the tile's part of the
+//      stream (the image is aligned to 16-byte units of the stream);
 //   4. the image is copied out with coalesced, byte-swapped 16-byte stores.
 // Stream words are owned by the tile that contains their first bit, so every
 // output word is written exactly once with a plain store: a tile completes
 // its last word by encoding up to 31 bits of the symbols that follow it and
 // skips the leading word it shares with its predecessor.
-// Codes longer than 25 bits do not fit a packed entry: their entry carries a
+// Codes longer than 32 bits do not fit a table entry: their entry carries a
 // flag and the length only, and a thread that meets one re-encodes its run
-// from the 64-bit table on a (rare, wave-divergent) side path.
+// from the 64-bit table in global memory (rare, wave-divergent).
 
 constexpr int ENC_THREADS = 512;
 constexpr int ENC_WAVES = ENC_THREADS / 64;
 constexpr int ENC_SPT = 32;
 constexpr int ENC_TILE = ENC_THREADS * ENC_SPT; // 16384 symbols
 constexpr int ENC_WINW = 5120;                  // words of stream image per pass (20 KiB)
-constexpr int ENC_REPL = 4;                     // replicas of the packed table in LDS
+constexpr int ENC_REPL = 4;                     // replicas of the {code, len} table in LDS
 constexpr int ENC_BATCH = 4;                    // consecutive tiles per workgroup
 constexpr int ENC_MIN_WAVES = 6;                // waves per SIMD the register budget allows
 constexpr uint32_t ENC_LONG_FLAG = 1u << 24;    // len word of a code above 32 bits: flag | len (four cannot wrap)

@@ -483,3 +483,30 @@ def test_build_gap_array_256mib_property(dev):
     nc, ns = dev.gap_layout(n, 64)
     assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
     assert torch.equal(so[:ns], enc.seg_off[:ns])
+
+
+# ----------------------------------- the benchmark configurations, full size
+
+@pytest.mark.parametrize("kind,gib", [("zipf", 1), ("uniform", 1), ("geometric", 4)])
+def test_full_size_round_trip_properties(dev, kind, gib):
+    # size-independent properties at the sizes the benchmark configurations name:
+    # the stream length is sum(hist * len), the gap array sums to it, the
+    # decode returns the input, and a second encode gives the same bytes
+    n = gib << 30
+    data = synth.generate_device(kind, n, seed=31)
+    hist = dev.histogram(data)
+    assert int(hist.sum()) == n
+    codes, lens = dev.build_codebook(hist)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(data, model)
+    assert enc.total_bits == int((hist * lens).sum())
+    nc, ns = dev.gap_layout(n, 64)
+    cb = enc.chunk_bits[:nc].to(torch.int32) & 0xffff
+    assert int(cb.sum(dtype=torch.int64)) == enc.total_bits
+    seg = cb.view(-1, 256).sum(dim=1, dtype=torch.int64).cumsum(0)
+    assert torch.equal(enc.seg_off[1:ns], seg[: ns - 1])
+    out = dev.decode(enc, model)
+    assert torch.equal(out, data)
+    del out
+    again = dev.encode(data, model)
+    assert torch.equal(again.stream(), enc.stream())
