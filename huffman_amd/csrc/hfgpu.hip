@@ -186,7 +186,7 @@ constexpr int ENC_WAVES = ENC_THREADS / 64;
 constexpr int ENC_SPT = 32;
 constexpr int ENC_TILE = ENC_THREADS * ENC_SPT; // 16384 symbols
 constexpr int ENC_WINW = 5120;                  // words of stream image per pass (20 KiB)
-constexpr int ENC_REPL = 4;                     // replicas of the {code, len} table in LDS
+constexpr int ENC_REPL = 1;                     // replicas of the {code, len} table in LDS
 constexpr int ENC_BATCH = 4;                    // consecutive tiles per workgroup
 constexpr int ENC_MIN_WAVES = 6;                // waves per SIMD the register budget allows
 constexpr uint32_t ENC_LONG_FLAG = 1u << 24;    // len word of a code above 32 bits: flag | len (four cannot wrap)
@@ -834,8 +834,8 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
     if (p.debug & 1u)
         return;
 
-    // ---- stage B: a rolled loop (one copy of the code); the tile's symbols are
-    // picked out of the batch's registers with selects on the loop counter
+    // ---- stage B: a rolled loop (one copy of the code) that always works on
+    // register set 0; the sets are rotated down after every tile
 #pragma unroll 1
     for (uint32_t t = 0; t < ENC_BATCH; ++t) {
         const uint32_t tile = tile0 + t;
@@ -844,13 +844,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
         // the table is read again here on purpose: without this fence the
         // compiler keeps all of stage A's lookups alive (in scratch) instead
         asm volatile("" ::: "memory");
-        uint32_t vc = 0, la = 0;
-#pragma unroll
-        for (int u = 0; u < ENC_BATCH; ++u) {
-            const uint32_t m = 0u - (uint32_t)(t == (uint32_t)u);
-            vc |= vcnt[u] & m;
-            la |= la_sym[u] & m;
-        }
+        const uint32_t vc = vcnt[0], la = la_sym[0];
         const uint64_t base = (uint64_t)tile * ENC_TILE;
         const uint64_t left = p.n - base;
         const uint64_t tile_end = base + (left < ENC_TILE ? left : (uint64_t)ENC_TILE);
@@ -891,7 +885,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
                 // common case, straight-line: the whole tile fits one image pass
                 if (my_bits && !(p.debug & 2u)) {
                     const bool done =
-                        enc_pack_thread<G, SPEC, FULL>(raw, t, vc, s_tab, stg, s_dump, s_lo + toff);
+                        enc_pack_thread<G, SPEC, FULL>(raw, 0, vc, s_tab, stg, s_dump, s_lo + toff);
                     if (SPEC && __builtin_expect(!done, 0)) // rare by the host's choice of G
                         enc_pack_thread_rolled(p, base + t0, vc, stg, s_lo + toff, my_bits, 0);
                 }
@@ -906,6 +900,14 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
             }
         }
         S = E;
+#pragma unroll
+        for (int u = 0; u + 1 < ENC_BATCH; ++u) {
+            vcnt[u] = vcnt[u + 1];
+            la_sym[u] = la_sym[u + 1];
+#pragma unroll
+            for (int q = 0; q < ENC_SPT / 4; ++q)
+                raw[u][q] = raw[u + 1][q];
+        }
     }
 }
 
