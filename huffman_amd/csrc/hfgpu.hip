@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "hfgpu.h"
@@ -970,6 +971,14 @@ struct LdsWords {
     const uint32_t *w;
     __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return w[i]; }
 };
+// LDS image with one unused slot after every 32 words, for streams whose
+// chunks all have (nearly) the same size -- 16 words for 8-bit codes: without
+// the padding all lanes of a wave would start on the same two banks.  Costs two
+// instructions per word read, so irregular streams keep the plain layout.
+struct SwzWords {
+    const uint32_t *w;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return w[i + (i >> 5)]; }
+};
 struct GlobalWords {
     const uint8_t *in;
     uint64_t in_bytes;
@@ -1244,11 +1253,12 @@ __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uin
 // its dependent table lookups, i.e. by the number of chunks in flight.
 // Lanes whose chunk is ragged (end of the stream) and segments too dense for
 // the image take a rolled loop that stores bytes straight to global memory.
-template <int CS, int K, bool ESC>
+template <int CS, int K, bool ESC, bool SWZ>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr uint32_t OROW = CS / 4 + 1; // +1: lanes start on different banks
+    using Img = typename std::conditional<SWZ, SwzWords, LdsWords>::type;
     const uint32_t lut_bytes = (p.lut_entries * 2u + 15u) & ~15u;
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
     uint32_t *img = reinterpret_cast<uint32_t *>(smem + lut_bytes); // input, then output
@@ -1272,7 +1282,6 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     const uint32_t nunits = (s_lo + total + 127u) / 128u + 1u; // +1: readers run ahead
     const bool use_lds = nunits * 4u <= (uint32_t)(HF_SEG_CHUNKS * CS / 4 + 16) && p.in_aligned16;
     if (use_lds) {
-        uint4 *dst = reinterpret_cast<uint4 *>(img);
         const uint64_t whole = p.in_bytes >> 4;
         const uint4 *src = reinterpret_cast<const uint4 *>(p.in);
         for (uint32_t i = threadIdx.x; i < nunits; i += DEC_THREADS) {
@@ -1287,7 +1296,12 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                 v.z = dec_load_word(p.in, p.in_bytes, u * 4 + 2);
                 v.w = dec_load_word(p.in, p.in_bytes, u * 4 + 3);
             }
-            dst[i] = v;
+            if (SWZ) { // word w of the image lives in slot w + w / 32 (see SwzWords)
+                uint32_t *dst = img + 4 * i + ((4 * i) >> 5);
+                dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+            } else {
+                reinterpret_cast<uint4 *>(img)[i] = v;
+            }
         }
     }
     __syncthreads();
@@ -1300,8 +1314,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     if (fast && K >= 8 && !ESC) {
         // codes of at most 8 bits: a streaming reader that merges one word per
         // 32 consumed bits touches LDS least (one word per four symbols)
-        LdsWords src{img};
-        BitReader<LdsWords> br(src, s_lo + excl);
+        Img src{img};
+        BitReader<Img> br(src, s_lo + excl);
         const uint32_t shift = 32 - p.w1;
 #pragma unroll
         for (int i = 0; i < CS / 4; ++i) {
@@ -1310,7 +1324,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             for (int k = 0; k < 4; ++k) {
                 if (k == 0)
                     br.refill();
-                pack |= dec_symbol<LdsWords, false>(br, s_lut, shift, p, bad) << (8 * k);
+                pack |= dec_symbol<Img, false>(br, s_lut, shift, p, bad) << (8 * k);
             }
             outw[i] = pack;
         }
@@ -1326,8 +1340,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             outw[i] = 0;
 #pragma unroll
         for (int g = 0; g < CS; g += K) {
-            const uint32_t *wp = img + (pos >> 5);
-            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const Img src{img};
+            const uint32_t wi = pos >> 5;
+            const uint32_t w0 = src(wi), w1 = src(wi + 1), w2 = src(wi + 2);
             const uint32_t sh = 32u - (pos & 31u); // 1..32
             const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
             const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
@@ -1795,6 +1810,7 @@ struct hf_model {
     bool enc_spec = false; // a merged group can exceed 32 bits
     bool has_encode = false;
     bool lut_escapes = false; // the decode table holds entries with the escape bit
+    bool regular_chunks = false; // 64 symbols are expected to differ by < 8 bits in length
 };
 
 namespace {
@@ -1900,6 +1916,17 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     mod->sentinel = lut.sentinel;
     mod->w1 = lut.w1;
     mod->lut_escapes = lut.has_escape;
+    // spread of a 64-symbol chunk's bit length when symbols occur with the
+    // probabilities 2^-len that the lengths imply
+    double kraft = 0, m1 = 0, m2 = 0;
+    for (uint64_t i = 0; i < m; ++i) {
+        const double w = std::ldexp(1.0, -(int)klens[i]);
+        kraft += w, m1 += w * klens[i], m2 += w * klens[i] * klens[i];
+    }
+    if (kraft > 0) {
+        m1 /= kraft, m2 /= kraft;
+        mod->regular_chunks = 64.0 * (m2 - m1 * m1) < 64.0; // standard deviation below 8 bits
+    }
     return HF_OK;
 }
 
@@ -2379,20 +2406,26 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     size_t lds = 0;
     if (chunk_syms == 64 && !(ctx->debug & 256)) {
         // register-output kernel: one LDS image serves as input, then as output
-        const uint32_t in_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
+        const uint32_t in_raw = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
+        const uint32_t in_words = in_raw + in_raw / 32 + 1; // padded slots, see SwzWords
         const uint32_t out_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
         p.istg_words = std::max(in_words, out_words);
         lds = lut_bytes + (size_t)(p.istg_words + 4) * 4;
         // symbols per window rebuild: K * sentinel <= 64
         const uint32_t k = 64u / std::max<uint32_t>(model->sentinel, 1u);
         if (model->lut_escapes)
-            kern = k >= 4 ? dec_kernel_reg<64, 4, true>
-                          : (k == 3 ? dec_kernel_reg<64, 3, true>
-                                    : (k == 2 ? dec_kernel_reg<64, 2, true>
-                                              : dec_kernel_reg<64, 1, true>));
+            kern = k >= 4 ? dec_kernel_reg<64, 4, true, false>
+                          : (k == 3 ? dec_kernel_reg<64, 3, true, false>
+                                    : (k == 2 ? dec_kernel_reg<64, 2, true, false>
+                                              : dec_kernel_reg<64, 1, true, false>));
+        else if (model->regular_chunks)
+            kern = k >= 8 ? dec_kernel_reg<64, 8, false, true>
+                          : (k >= 6 ? dec_kernel_reg<64, 6, false, true>
+                                    : dec_kernel_reg<64, 5, false, true>);
         else
-            kern = k >= 8 ? dec_kernel_reg<64, 8, false>
-                          : (k >= 6 ? dec_kernel_reg<64, 6, false> : dec_kernel_reg<64, 5, false>);
+            kern = k >= 8 ? dec_kernel_reg<64, 8, false, false>
+                          : (k >= 6 ? dec_kernel_reg<64, 6, false, false>
+                                    : dec_kernel_reg<64, 5, false, false>);
     } else {
         p.istg_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
         const uint32_t ostg_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
