@@ -266,6 +266,52 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
     return HF_OK;
 }
 
+uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t m,
+                            uint32_t sentinel)
+{
+    if (m == 0 || sentinel == 0 || sentinel > 64)
+        return 0;
+    // prefix free: no code is the beginning of another one
+    for (uint64_t i = 0; i < m; ++i) {
+        if (klens[i] == 0 || klens[i] > sentinel)
+            return 0;
+        for (uint64_t j = 0; j < m; ++j) {
+            if (i == j || klens[j] < klens[i])
+                continue;
+            const uint32_t drop = sentinel - klens[i];
+            if ((keys[j] >> drop) == (keys[i] >> drop))
+                return 0;
+        }
+    }
+    double d[65] = {0};
+    double kraft = 0;
+    for (uint64_t i = 0; i < m; ++i) {
+        const double w = std::ldexp(1.0, -(int)klens[i]);
+        d[klens[i]] += w;
+        kraft += w;
+    }
+    for (double &x : d)
+        x /= kraft;
+    for (uint32_t k : {16u, 8u}) {
+        if (k * sentinel <= 64)
+            return 0; // the plain K = 64 / sentinel is at least as wide
+        double c[66] = {0}; // P(sum of lengths = a), everything above 64 lumped in c[65]
+        c[0] = 1.0;
+        for (uint32_t i = 0; i < k; ++i) {
+            double nc[66] = {0};
+            for (int a = 0; a <= 65; ++a)
+                for (int l = 1; l <= 64; ++l)
+                    if (c[a] != 0 && d[l] != 0)
+                        nc[std::min(a + l, 65)] += c[a] * d[l];
+            std::memcpy(c, nc, sizeof(c));
+        }
+        const double p_chunk = 1.0 - std::pow(1.0 - c[65], 64.0 / k);
+        if (p_chunk <= 1e-7)
+            return k;
+    }
+    return 0;
+}
+
 int pick_merge_width(const uint64_t lens[256], bool *speculative)
 {
     double d[65] = {0}; // distribution of the code length of one symbol

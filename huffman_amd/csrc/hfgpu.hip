@@ -1253,7 +1253,7 @@ __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uin
 // its dependent table lookups, i.e. by the number of chunks in flight.
 // Lanes whose chunk is ragged (end of the stream) and segments too dense for
 // the image take a rolled loop that stores bytes straight to global memory.
-template <int CS, int K, bool ESC, bool SWZ>
+template <int CS, int K, bool ESC, bool SWZ, bool SPEC>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -1311,7 +1311,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     const bool fast = use_lds && cnt == (uint32_t)CS;
     uint32_t outw[CS / 4];
     bool bad = false;
-    if (fast && K >= 8 && !ESC) {
+    bool dirty = false; // SPEC: some group of K codes ran past its 64-bit window
+    if (fast && K >= 8 && !ESC && !SPEC) {
         // codes of at most 8 bits: a streaming reader that merges one word per
         // 32 consumed bits touches LDS least (one word per four symbols)
         Img src{img};
@@ -1330,9 +1331,11 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
         }
     } else if (fast) {
         // No reader state besides the bit position: every K symbols the lane
-        // rebuilds a 64-bit window from the three image words at its position
-        // (K * sentinel <= 64, so the window never runs dry in between) -- no
-        // refill branches, and the table has no escape entries to test for.
+        // rebuilds a 64-bit window from the three image words at its position;
+        // no refill branches.  Either K * sentinel <= 64, so the window cannot
+        // run dry, or (SPEC, prefix-free models only) the host chose K so that
+        // K codes practically never exceed 64 bits; a lane to which it happens
+        // anyway is marked dirty and decodes its chunk again at the end.
         uint32_t pos = s_lo + excl;
         const uint32_t shift = 32 - p.w1;
 #pragma unroll
@@ -1365,6 +1368,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                 }
             }
             pos += used;
+            if (SPEC)
+                dirty = dirty || used > 64u;
         }
     } else if (cnt) {
         // ragged chunk or oversized segment: bytes go straight to global memory
@@ -1376,7 +1381,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             p.out[sym0 + i] = (uint8_t)dec_symbol<GlobalWords, true>(br, s_lut, shift, p, bad);
         }
     }
-    if (bad)
+    if (bad && !dirty) // a dirty lane's symbols (and errors) are not real: it decodes again below
         atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
     __syncthreads(); // every lane is done with the compressed image: reuse it for the output
     if (fast) {
@@ -1407,6 +1412,22 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
             for (uint32_t i = 0; i < 16u; ++i)
                 p.out[obase + o + i] = (uint8_t)(vv[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+    if (SPEC) {
+        __syncthreads(); // the chunk's (wrong) bytes from the image have been stored
+        if (dirty) {
+            GlobalWords src{p.in, p.in_bytes, ubase * 4};
+            BitReader<GlobalWords> br(src, s_lo + excl);
+            const uint32_t shift = 32 - p.w1;
+            bool bad2 = false;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                br.refill();
+                p.out[sym0 + i] = (uint8_t)dec_symbol<GlobalWords, true>(br, s_lut, shift, p, bad2);
+            }
+            if (bad2)
+                atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
+                         (unsigned long long)HF_FLAG_DECODE);
         }
     }
 }
@@ -1811,6 +1832,7 @@ struct hf_model {
     bool has_encode = false;
     bool lut_escapes = false; // the decode table holds entries with the escape bit
     bool regular_chunks = false; // 64 symbols are expected to differ by < 8 bits in length
+    uint32_t dec_spec_k = 0; // 16 or 8: codes per 64-bit window the decoder may assume (else 0)
 };
 
 namespace {
@@ -1927,6 +1949,7 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
         m1 /= kraft, m2 /= kraft;
         mod->regular_chunks = 64.0 * (m2 - m1 * m1) < 64.0; // standard deviation below 8 bits
     }
+    mod->dec_spec_k = hf::pick_decode_window(keys, klens, m, lut.sentinel);
     return HF_OK;
 }
 
@@ -2411,21 +2434,28 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
         const uint32_t out_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
         p.istg_words = std::max(in_words, out_words);
         lds = lut_bytes + (size_t)(p.istg_words + 4) * 4;
-        // symbols per window rebuild: K * sentinel <= 64
+        // symbols per window rebuild: K * sentinel <= 64, or the model's speculative K
         const uint32_t k = 64u / std::max<uint32_t>(model->sentinel, 1u);
-        if (model->lut_escapes)
-            kern = k >= 4 ? dec_kernel_reg<64, 4, true, false>
-                          : (k == 3 ? dec_kernel_reg<64, 3, true, false>
-                                    : (k == 2 ? dec_kernel_reg<64, 2, true, false>
-                                              : dec_kernel_reg<64, 1, true, false>));
+        if (model->dec_spec_k >= 8 && model->dec_spec_k > k) {
+            if (model->lut_escapes)
+                kern = model->dec_spec_k >= 16 ? dec_kernel_reg<64, 16, true, false, true>
+                                               : dec_kernel_reg<64, 8, true, false, true>;
+            else
+                kern = model->dec_spec_k >= 16 ? dec_kernel_reg<64, 16, false, false, true>
+                                               : dec_kernel_reg<64, 8, false, false, true>;
+        } else if (model->lut_escapes)
+            kern = k >= 4 ? dec_kernel_reg<64, 4, true, false, false>
+                          : (k == 3 ? dec_kernel_reg<64, 3, true, false, false>
+                                    : (k == 2 ? dec_kernel_reg<64, 2, true, false, false>
+                                              : dec_kernel_reg<64, 1, true, false, false>));
         else if (model->regular_chunks)
-            kern = k >= 8 ? dec_kernel_reg<64, 8, false, true>
-                          : (k >= 6 ? dec_kernel_reg<64, 6, false, true>
-                                    : dec_kernel_reg<64, 5, false, true>);
+            kern = k >= 8 ? dec_kernel_reg<64, 8, false, true, false>
+                          : (k >= 6 ? dec_kernel_reg<64, 6, false, true, false>
+                                    : dec_kernel_reg<64, 5, false, true, false>);
         else
-            kern = k >= 8 ? dec_kernel_reg<64, 8, false, false>
-                          : (k >= 6 ? dec_kernel_reg<64, 6, false, false>
-                                    : dec_kernel_reg<64, 5, false, false>);
+            kern = k >= 8 ? dec_kernel_reg<64, 8, false, false, false>
+                          : (k >= 6 ? dec_kernel_reg<64, 6, false, false, false>
+                                    : dec_kernel_reg<64, 5, false, false, false>);
     } else {
         p.istg_words = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
         const uint32_t ostg_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
