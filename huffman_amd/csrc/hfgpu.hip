@@ -2427,7 +2427,8 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     const int spr = model->sentinel <= 8 ? 4 : (model->sentinel <= 16 ? 2 : 1);
     void (*kern)(DecParams) = nullptr;
     size_t lds = 0;
-    if (chunk_syms == 64 && !(ctx->debug & 256)) {
+    const bool reg128 = chunk_syms == 128 && !model->lut_escapes;
+    if ((chunk_syms == 64 || reg128) && !(ctx->debug & 256)) {
         // register-output kernel: one LDS image serves as input, then as output
         const uint32_t in_raw = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
         const uint32_t in_words = in_raw + in_raw / 32 + 1; // padded slots, see SwzWords
@@ -2436,7 +2437,13 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
         lds = lut_bytes + (size_t)(p.istg_words + 4) * 4;
         // symbols per window rebuild: K * sentinel <= 64, or the model's speculative K
         const uint32_t k = 64u / std::max<uint32_t>(model->sentinel, 1u);
-        if (model->dec_spec_k >= 8 && model->dec_spec_k > k) {
+        if (reg128)
+            kern = model->regular_chunks
+                       ? (k >= 6 ? dec_kernel_reg<128, 6, false, true, false>
+                                 : dec_kernel_reg<128, 5, false, true, false>)
+                       : (k >= 6 ? dec_kernel_reg<128, 6, false, false, false>
+                                 : dec_kernel_reg<128, 5, false, false, false>);
+        else if (model->dec_spec_k >= 8 && model->dec_spec_k > k) {
             if (model->lut_escapes)
                 kern = model->dec_spec_k >= 16 ? dec_kernel_reg<64, 16, true, false, true>
                                                : dec_kernel_reg<64, 8, true, false, true>;
