@@ -236,12 +236,24 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
         // window ends inside this table the rest of the index is don't-care.
         const uint32_t sig = std::min(job.width, s - job.depth);
         const uint32_t rem = s - job.depth - sig; // window bits below this slot
+        // largest key <= the first slot's low end (or the first key), then swept forward
+        int64_t cur_lo = predecessor(keys, m, (job.prefix << sig) << rem);
+        if (cur_lo < 0)
+            cur_lo = 0;
+        int64_t cur_hi = cur_lo;
         for (uint32_t i = 0; i < (1u << job.width); ++i) {
             const uint64_t part = i >> (job.width - sig);
             const uint64_t lo = ((job.prefix << sig) | part) << rem;
             const uint64_t hi = lo + (((uint64_t)1 << rem) - 1);
-            const int64_t plo = predecessor(keys, m, lo);
-            const int64_t phi = predecessor(keys, m, hi);
+            // lo and hi grow with i: the predecessors only ever move forward
+            while (cur_lo + 1 < (int64_t)m && keys[cur_lo + 1] <= lo)
+                ++cur_lo;
+            if (cur_hi < cur_lo)
+                cur_hi = cur_lo;
+            while (cur_hi + 1 < (int64_t)m && keys[cur_hi + 1] <= hi)
+                ++cur_hi;
+            const int64_t plo = (cur_lo >= 0 && keys[cur_lo] <= lo) ? cur_lo : -1;
+            const int64_t phi = (cur_hi >= 0 && keys[cur_hi] <= hi) ? cur_hi : -1;
             uint16_t e;
             if (phi < 0) {
                 e = HF_LUT_INVALID;
@@ -269,45 +281,56 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
 uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t m,
                             uint32_t sentinel)
 {
-    if (m == 0 || sentinel == 0 || sentinel > 64)
-        return 0;
-    // prefix free: no code is the beginning of another one
+    if (m == 0 || sentinel == 0 || sentinel > 64 || 8 * sentinel <= 64)
+        return 0; // the plain K = 64 / sentinel is at least 8 wide already
+    // prefix free: with the keys (left-aligned codes) in ascending order, no key
+    // may fall inside the range its predecessor's code covers
     for (uint64_t i = 0; i < m; ++i) {
         if (klens[i] == 0 || klens[i] > sentinel)
             return 0;
-        for (uint64_t j = 0; j < m; ++j) {
-            if (i == j || klens[j] < klens[i])
-                continue;
-            const uint32_t drop = sentinel - klens[i];
-            if ((keys[j] >> drop) == (keys[i] >> drop))
+        if (i + 1 < m) {
+            const uint64_t span = (uint64_t)1 << (sentinel - klens[i]);
+            if (keys[i + 1] <= keys[i] || keys[i + 1] - keys[i] < span)
                 return 0;
         }
     }
     double d[65] = {0};
     double kraft = 0;
+    int present[64], np = 0;
     for (uint64_t i = 0; i < m; ++i) {
         const double w = std::ldexp(1.0, -(int)klens[i]);
+        if (d[klens[i]] == 0)
+            present[np++] = klens[i];
         d[klens[i]] += w;
         kraft += w;
     }
     for (double &x : d)
         x /= kraft;
-    for (uint32_t k : {16u, 8u}) {
-        if (k * sentinel <= 64)
-            return 0; // the plain K = 64 / sentinel is at least as wide
-        double c[66] = {0}; // P(sum of lengths = a), everything above 64 lumped in c[65]
-        c[0] = 1.0;
-        for (uint32_t i = 0; i < k; ++i) {
-            double nc[66] = {0};
-            for (int a = 0; a <= 65; ++a)
-                for (int l = 1; l <= 64; ++l)
-                    if (c[a] != 0 && d[l] != 0)
-                        nc[std::min(a + l, 65)] += c[a] * d[l];
-            std::memcpy(c, nc, sizeof(c));
+    // P(sum of lengths = a) after 8 and after 16 codes, everything above 64 in c[65]
+    double c[66] = {0};
+    c[0] = 1.0;
+    double over[2] = {1.0, 1.0};
+    for (uint32_t i = 1; i <= 16; ++i) {
+        double nc[66] = {0};
+        for (int a = 0; a <= 65; ++a) {
+            if (c[a] == 0)
+                continue;
+            for (int q = 0; q < np; ++q)
+                nc[std::min(a + present[q], 65)] += c[a] * d[present[q]];
         }
-        const double p_chunk = 1.0 - std::pow(1.0 - c[65], 64.0 / k);
+        std::memcpy(c, nc, sizeof(c));
+        if (i == 8)
+            over[1] = c[65];
+        if (i == 16)
+            over[0] = c[65];
+    }
+    const uint32_t widths[2] = {16u, 8u};
+    for (int t = 0; t < 2; ++t) {
+        if (widths[t] * sentinel <= 64)
+            continue;
+        const double p_chunk = 1.0 - std::pow(1.0 - over[t], 64.0 / widths[t]);
         if (p_chunk <= 1e-7)
-            return k;
+            return widths[t];
     }
     return 0;
 }

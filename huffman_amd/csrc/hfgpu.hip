@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "hfgpu.h"
@@ -1808,6 +1809,9 @@ struct hf_ctx {
     int hist_grid = 0;
     int timeout_ms = 2000;
     int debug = 0;
+    // device blocks of destroyed models, kept for the next hf_model_create: a
+    // codec that builds a model per stream would otherwise pay hipMalloc/hipFree each time
+    std::vector<std::pair<void *, size_t>> blob_cache;
     void *arena = nullptr; // device staging of the *_host entry points (grow only)
     size_t arena_bytes = 0;
 };
@@ -1815,6 +1819,7 @@ struct hf_ctx {
 struct hf_model {
     hf_ctx *ctx = nullptr;
     void *d_blob = nullptr;
+    size_t blob_bytes = 0;
     uint64_t *d_enc = nullptr;   // 256 x (code << 6 | len)
     uint2 *d_enc2 = nullptr;     // 256 x {code, len} ({0, ENC_LONG_FLAG | len} above 32 bits)
     uint8_t *d_len8 = nullptr;   // 256 x len
@@ -1923,7 +1928,18 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     std::memcpy(blob.data() + off_keys, keys, m * sizeof(uint64_t));
     std::memcpy(blob.data() + off_ksyms, syms, m);
     std::memcpy(blob.data() + off_klens, klens, m);
-    HF_HIP(ctx, hipMalloc(&mod->d_blob, total));
+    for (size_t i = 0; i < ctx->blob_cache.size(); ++i) {
+        if (ctx->blob_cache[i].second >= total) {
+            mod->d_blob = ctx->blob_cache[i].first;
+            mod->blob_bytes = ctx->blob_cache[i].second;
+            ctx->blob_cache.erase(ctx->blob_cache.begin() + (long)i);
+            break;
+        }
+    }
+    if (!mod->d_blob) {
+        mod->blob_bytes = align_up(total, 4096);
+        HF_HIP(ctx, hipMalloc(&mod->d_blob, mod->blob_bytes));
+    }
     HF_HIP(ctx, hipMemcpy(mod->d_blob, blob.data(), total, hipMemcpyHostToDevice));
     uint8_t *b = static_cast<uint8_t *>(mod->d_blob);
     mod->d_enc = reinterpret_cast<uint64_t *>(b + off_enc);
@@ -2017,6 +2033,8 @@ int hf_ctx_destroy(hf_ctx *ctx)
         (void)hipFree(ctx->scratch);
     if (ctx->arena)
         (void)hipFree(ctx->arena);
+    for (auto &b : ctx->blob_cache)
+        (void)hipFree(b.first);
     if (ctx->d_result)
         (void)hipFree(ctx->d_result);
     delete ctx;
@@ -2201,8 +2219,11 @@ int hf_model_destroy(hf_model *model)
         return HF_OK;
     if (model->d_blob) {
         (void)hipSetDevice(model->ctx->device);
-        (void)hipStreamSynchronize(model->ctx->stream);
-        (void)hipFree(model->d_blob);
+        (void)hipStreamSynchronize(model->ctx->stream); // no kernel reads the tables any more
+        if (model->ctx->blob_cache.size() < 4)
+            model->ctx->blob_cache.emplace_back(model->d_blob, model->blob_bytes);
+        else
+            (void)hipFree(model->d_blob);
     }
     delete model;
     return HF_OK;
