@@ -274,9 +274,16 @@ __device__ __forceinline__ uint32_t enc_sum_lens(const uint32_t raw[ENC_SPT / 4]
 }
 
 // OR `len` bits of `code` into the stream image at image bit `bitpos`.
-__device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos, uint64_t code,
-                                            uint32_t len, uint32_t wlo, uint32_t whi,
-                                            uint32_t clip)
+// LDS slot of image word w: one slot is left unused after every 32 words.
+// Threads that produce the same number of words each (eight for 8-bit codes)
+// would otherwise OR into the same few banks at the same time; irregular
+// streams gain a little as well.
+__device__ __forceinline__ uint32_t enc_slot(uint32_t w) { return w + (w >> 5); }
+constexpr int ENC_IMG_SLOTS = ENC_WINW + ENC_WINW / 32 + 4;
+
+__device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos,
+                                            uint64_t code, uint32_t len, uint32_t wlo,
+                                            uint32_t whi, uint32_t clip)
 {
     if (bitpos + len > clip) { // keep only the bits in front of image bit `clip`
         const uint32_t keep = clip > bitpos ? clip - bitpos : 0u;
@@ -289,7 +296,7 @@ __device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos, uint
         const uint32_t part =
             (uint32_t)(code >> (len - take)) & (take == 32 ? ~0u : ((1u << take) - 1u));
         if (w >= wlo && w < whi)
-            __hip_atomic_fetch_or(stg + (w - wlo), part << (32u - o - take), __ATOMIC_RELAXED,
+            __hip_atomic_fetch_or(stg + enc_slot(w - wlo), part << (32u - o - take), __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         bitpos += take;
         len -= take;
@@ -311,7 +318,8 @@ struct EncSink {
     __device__ __forceinline__ void emit(uint32_t val)
     {
         if (w < (uint32_t)ENC_WINW)
-            __hip_atomic_fetch_or(stg + w, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(stg + enc_slot(w), val, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
         ++w;
     }
     __device__ __forceinline__ void append(uint32_t code, uint32_t len) // len <= 32
@@ -335,15 +343,17 @@ struct EncSink {
 // others OR a don't-care value into a private dump slot behind the image, so
 // the wave never diverges and never waits on a scalar branch.
 struct EncSinkFlat {
-    uint32_t *ptr;  // image word being filled
+    uint32_t *stg;
+    uint32_t w;     // image word being filled
     uint32_t *dump; // this lane's dump slot
     uint32_t nb;
     uint64_t acc;
     bool alive; // once cleared, everything goes to the dump slot
-    __device__ __forceinline__ EncSinkFlat(uint32_t *stg, uint32_t *dumps, uint32_t bitpos)
-        : ptr(stg + (bitpos >> 5)), dump(dumps + threadIdx.x), nb(bitpos & 31u), acc(0), alive(true)
+    __device__ __forceinline__ EncSinkFlat(uint32_t *s, uint32_t *dumps, uint32_t bitpos)
+        : stg(s), w(bitpos >> 5), dump(dumps + threadIdx.x), nb(bitpos & 31u), acc(0), alive(true)
     {
     }
+    __device__ __forceinline__ uint32_t *slot() const { return stg + enc_slot(w); }
     __device__ __forceinline__ void append(uint32_t code, uint32_t len) // len <= 32
     {
         acc = (acc << (len & 63u)) | code;
@@ -351,14 +361,14 @@ struct EncSinkFlat {
         const bool full = nb >= 32 && alive;
         nb &= 31u;
         const uint32_t word = (uint32_t)(acc >> nb);
-        __hip_atomic_fetch_or(full ? ptr : dump, word, __ATOMIC_RELAXED,
+        __hip_atomic_fetch_or(full ? slot() : dump, word, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_WORKGROUP);
-        ptr += full ? 1 : 0;
+        w += full ? 1 : 0;
     }
     __device__ __forceinline__ void finish()
     {
         const uint32_t word = nb ? (uint32_t)(acc << (32 - nb)) : 0u;
-        __hip_atomic_fetch_or(alive ? ptr : dump, word, __ATOMIC_RELAXED,
+        __hip_atomic_fetch_or(alive ? slot() : dump, word, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
@@ -673,10 +683,12 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
     const uint64_t ua = (gbase + wlo) >> 2, ub = (gb + 3) >> 2;
     for (uint64_t u = ua + threadIdx.x; u < ub; u += ENC_THREADS) {
         const uint32_t j = (uint32_t)((u << 2) - gbase) - wlo; // image word of the unit
-        const uint4 v = *reinterpret_cast<const uint4 *>(stg + j);
         // the thread that copies a unit out also clears it: the image is all
         // zero again when the pass ends, without a separate sweep
-        *reinterpret_cast<uint4 *>(stg + j) = make_uint4(0, 0, 0, 0);
+        // (the unit's four words share a 32-word row, so their slots are adjacent)
+        uint32_t *src = stg + enc_slot(j);
+        const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+        src[0] = 0, src[1] = 0, src[2] = 0, src[3] = 0;
         const uint32_t vals[4] = {bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)};
         const uint64_t b = u << 4;
         if ((u << 2) >= ga && (u << 2) + 4 <= gb && b + 16 <= limit && b + 16 <= p.out_cap &&
@@ -729,7 +741,7 @@ template <int G, bool SPEC, bool FULL>
 __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(EncParams p)
 {
     const bool CHAINED = p.desc != nullptr; // else: tile offsets come from the scan kernel
-    __shared__ __align__(16) uint32_t stg[ENC_WINW];
+    __shared__ __align__(16) uint32_t stg[ENC_IMG_SLOTS];
     __shared__ uint2 s_tab[256 * ENC_REPL];
     __shared__ __align__(16) uint8_t s_len[256];
     __shared__ uint32_t s_dump[ENC_THREADS]; // per-lane don't-care slots of the flat sink
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
             s_batch = p.first_batch + ((p.debug & 4u) ? blockIdx.x : atomicAdd(p.ticket, 1u));
     }
     enc_stage_table(p, s_tab, s_len);
-    for (uint32_t i = threadIdx.x; i < ENC_WINW / 4; i += ENC_THREADS)
+    for (uint32_t i = threadIdx.x; i < sizeof(stg) / 16; i += ENC_THREADS)
         reinterpret_cast<uint4 *>(stg)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t batch = CHAINED ? s_batch : p.first_batch + blockIdx.x;
