@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--enc-mode", type=int, default=1)
     ap.add_argument("--gather", action="store_true", help="also gather the shards to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=int, default=128)
+    ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--seed", type=int, default=2024)
     return ap.parse_args()
 
