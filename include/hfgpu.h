@@ -75,8 +75,12 @@ HF_API int hf_ctx_destroy(hf_ctx *ctx);
 HF_API int hf_ctx_set_stream(hf_ctx *ctx, void *stream);
 HF_API int hf_ctx_synchronize(hf_ctx *ctx);
 HF_API const char *hf_last_error(const hf_ctx *ctx);
-/* Tuning knobs for experiments: name in {"enc_mode" (0 = three kernels,
- * 1 = single pass with chained scan), "hist_grid", "timeout_ms"}. */
+/* Knobs: "enc_mode" (1 = single pass with a chained scan between workgroups,
+ * the default; 0 = three kernels, no waiting between workgroups),
+ * "hist_grid" (workgroups of the histogram kernel, 0 = four per CU),
+ * "timeout_ms" (bound on the waits of the chained scan; when it expires the
+ * call returns HF_ERR_INTERNAL), "debug" (bit mask that skips phases of the
+ * encoder for timing experiments -- results are then wrong on purpose). */
 HF_API int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value);
 
 /* -------------------------------------------------------- L0: src/stats.rs */
