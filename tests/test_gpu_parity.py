@@ -510,3 +510,54 @@ def test_full_size_round_trip_properties(dev, kind, gib):
     del out
     again = dev.encode(data, model)
     assert torch.equal(again.stream(), enc.stream())
+
+
+# ------------------------------------------------------------ random models
+
+def _random_histogram(rng):
+    kind = rng.integers(0, 6)
+    nsym = int(rng.integers(1, 257))
+    syms = rng.permutation(256)[:nsym]
+    hist = np.zeros(256, dtype=np.uint64)
+    if kind == 0:      # flat
+        hist[syms] = rng.integers(1, 4, size=nsym)
+    elif kind == 1:    # geometric: long codes
+        hist[syms] = np.maximum(1, (2.0 ** (40 - 1.0 * np.arange(nsym))).astype(np.uint64))
+    elif kind == 2:    # Fibonacci: the longest codes a histogram can give
+        fib = [1, 1]
+        while len(fib) < min(nsym, 50):
+            fib.append(fib[-1] + fib[-2])
+        fib = fib[: nsym]
+        hist[syms[: len(fib)]] = fib[::-1]
+    elif kind == 3:    # Zipf with a random exponent
+        hist[syms] = np.maximum(1, (1e9 / (np.arange(nsym) + 1.0) ** rng.uniform(0.5, 2.5))).astype(np.uint64)
+    elif kind == 4:    # two levels
+        hist[syms] = rng.choice([1, 1000], size=nsym)
+    else:              # random counts
+        hist[syms] = rng.integers(1, 1 << 20, size=nsym)
+    return hist, syms
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_models_and_inputs(dev, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    hist, syms = _random_histogram(rng)
+    codes, lens = orc.generate_extended_codewords(hist)
+    if lens.max() > 57:
+        pytest.skip("longer than the codec takes")
+    n = int(rng.choice([1, 63, 64, 65, 1000, 16384, 16385, 50001, 150000]))
+    # symbols drawn by the model's weights, with runs of the rarest ones mixed in
+    p = hist[syms].astype(np.float64)
+    data = rng.choice(syms, size=n, p=p / p.sum()).astype(np.uint8)
+    live = syms[hist[syms] > 0]
+    rare = live[np.argsort(hist[live])[: 3]]
+    for _ in range(int(rng.integers(0, 4))):
+        at = int(rng.integers(0, n))
+        data[at: at + int(rng.integers(1, 200))] = rng.choice(rare)
+    cs = int(rng.choice([64, 64, 128, 256]))
+    model, enc = check_encode(dev, orc, data, codes, lens, chunk_syms=cs, mode=int(rng.integers(0, 2)))
+    assert np.array_equal(dev.decode(enc, model).cpu().numpy(), data)
+    cb, so = dev.build_gap_array(enc.data, enc.nbytes, model, n, cs)
+    nc, ns = dev.gap_layout(n, cs)
+    assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
+    assert torch.equal(so[:ns], enc.seg_off[:ns])
