@@ -338,38 +338,35 @@ struct EncSink {
     }
 };
 
-// The same sink without branches, for the single-pass fast path: every append
-// issues one LDS OR.  A lane whose word is complete ORs it into the image; the
-// others OR a don't-care value into a private dump slot behind the image, so
-// the wave never diverges and never waits on a scalar branch.
+// The sink of the single-pass fast path: straight-line code in which only the
+// LDS OR itself is predicated (lanes whose word is not complete yet sit the
+// instruction out), and the image slot is computed from a word index.
 struct EncSinkFlat {
     uint32_t *stg;
-    uint32_t w;     // image word being filled
-    uint32_t *dump; // this lane's dump slot
+    uint32_t w; // image word being filled
     uint32_t nb;
     uint64_t acc;
-    bool alive; // once cleared, everything goes to the dump slot
-    __device__ __forceinline__ EncSinkFlat(uint32_t *s, uint32_t *dumps, uint32_t bitpos)
-        : stg(s), w(bitpos >> 5), dump(dumps + threadIdx.x), nb(bitpos & 31u), acc(0), alive(true)
+    bool alive; // once cleared, nothing is written any more
+    __device__ __forceinline__ EncSinkFlat(uint32_t *s, uint32_t bitpos)
+        : stg(s), w(bitpos >> 5), nb(bitpos & 31u), acc(0), alive(true)
     {
     }
-    __device__ __forceinline__ uint32_t *slot() const { return stg + enc_slot(w); }
     __device__ __forceinline__ void append(uint32_t code, uint32_t len) // len <= 32
     {
         acc = (acc << (len & 63u)) | code;
         nb += len;
         const bool full = nb >= 32 && alive;
         nb &= 31u;
-        const uint32_t word = (uint32_t)(acc >> nb);
-        __hip_atomic_fetch_or(full ? slot() : dump, word, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (full)
+            __hip_atomic_fetch_or(stg + enc_slot(w), (uint32_t)(acc >> nb), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
         w += full ? 1 : 0;
     }
     __device__ __forceinline__ void finish()
     {
-        const uint32_t word = nb ? (uint32_t)(acc << (32 - nb)) : 0u;
-        __hip_atomic_fetch_or(alive ? slot() : dump, word, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nb && alive)
+            __hip_atomic_fetch_or(stg + enc_slot(w), (uint32_t)(acc << (32 - nb)),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
 
@@ -425,11 +422,11 @@ __device__ __forceinline__ uint32_t enc_pick(const uint32_t (&raw)[ENC_BATCH][EN
 template <int G, bool SPEC, bool FULL>
 __device__ __forceinline__ bool enc_pack_thread(const uint32_t (&raw)[ENC_BATCH][ENC_SPT / 4],
                                                 uint32_t t, uint32_t vcnt, const uint2 *s_tab2,
-                                                uint32_t *stg, uint32_t *dumps, uint32_t bitpos)
+                                                uint32_t *stg, uint32_t bitpos)
 {
     constexpr int LG = 4; // lookups per group = the four symbols of one input dword
     const uint2 *tab = s_tab2 + (threadIdx.x & (ENC_REPL - 1));
-    EncSinkFlat sink(stg, dumps, bitpos);
+    EncSinkFlat sink(stg, bitpos);
     uint2 cur[LG], nxt[LG];
     auto fetch = [&](uint2 e[LG], int q) {
         const uint32_t dw = enc_pick(raw, t, q); // the four symbols of this group
@@ -744,7 +741,6 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
     __shared__ __align__(16) uint32_t stg[ENC_IMG_SLOTS];
     __shared__ uint2 s_tab[256 * ENC_REPL];
     __shared__ __align__(16) uint8_t s_len[256];
-    __shared__ uint32_t s_dump[ENC_THREADS]; // per-lane don't-care slots of the flat sink
     __shared__ uint32_t s_toff[ENC_BATCH][ENC_THREADS + 1];
     __shared__ uint32_t s_wave[ENC_BATCH][ENC_WAVES];
     __shared__ uint64_t s_start;
@@ -899,7 +895,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
                 // common case, straight-line: the whole tile fits one image pass
                 if (my_bits && !(p.debug & 2u)) {
                     const bool done =
-                        enc_pack_thread<G, SPEC, FULL>(raw, 0, vc, s_tab, stg, s_dump, s_lo + toff);
+                        enc_pack_thread<G, SPEC, FULL>(raw, 0, vc, s_tab, stg, s_lo + toff);
                     if (SPEC && __builtin_expect(!done, 0)) // rare by the host's choice of G
                         enc_pack_thread_rolled(p, base + t0, vc, stg, s_lo + toff, my_bits, 0);
                 }
