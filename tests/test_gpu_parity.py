@@ -561,3 +561,39 @@ def test_random_models_and_inputs(dev, orc, seed):
     nc, ns = dev.gap_layout(n, cs)
     assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
     assert torch.equal(so[:ns], enc.seg_off[:ns])
+
+
+# ------------------------------------------------- buffers that are not 16-byte aligned
+
+@pytest.mark.parametrize("in_off,out_off", [(1, 0), (3, 4), (13, 8), (0, 12), (16, 4)])
+def test_unaligned_buffers(dev, orc, in_off, out_off):
+    n = 3 * 16384 * 4 + 777
+    data = synth.generate_host("zipf", n, seed=in_off * 31 + out_off)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    want, _ = orc.encode_slice(data, codes, lens)
+    model = dev.DeviceModel(codes, lens)
+    src = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    src[in_off: in_off + n] = to_gpu(data)
+    bufs = dev.EncodeBuffers(model, n, 64)
+    big = torch.zeros(bufs.cap + 64, dtype=torch.uint8, device="cuda")
+    bufs.data = big[out_off: out_off + bufs.cap]          # 4-byte aligned, mostly not 16
+    dev.encode_async(src[in_off: in_off + n], model, bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.result[1].item()) == 0
+    bits = int(bufs.result[0].item())
+    nbytes = (bits + 7) // 8
+    assert nbytes == want.size
+    assert np.array_equal(bufs.data[:nbytes].cpu().numpy(), want)
+    # decode from a stream at a 4-byte offset into an output at an odd offset
+    comp = torch.zeros(nbytes + 64, dtype=torch.uint8, device="cuda")
+    comp[out_off: out_off + nbytes] = bufs.data[:nbytes]
+    out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    res = torch.zeros(4, dtype=torch.int64, device="cuda")
+    dev.decode_async(comp[out_off:], nbytes, model, n, 64, bufs.chunk_bits, bufs.seg_off,
+                     out[in_off: in_off + n], res)
+    torch.cuda.synchronize()
+    assert int(res[1].item()) == 0
+    assert np.array_equal(out[in_off: in_off + n].cpu().numpy(), data)
+    cb, so = dev.build_gap_array(comp[out_off:], nbytes, model, n)
+    nc, ns = dev.gap_layout(n, 64)
+    assert torch.equal(cb[:nc], bufs.chunk_bits[:nc]) and torch.equal(so[:ns], bufs.seg_off[:ns])
