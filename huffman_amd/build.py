@@ -69,6 +69,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     dev = [hipcc(), "--offload-arch=gfx950", *common, *inc, "-c", SOURCES[0], "-o", objs[0]]
     if verbose:
         dev.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    if os.environ.get("HF_ENC_TRACE") == "1":  # phase stamps in the encode kernel (tools/trace_enc.py)
+        dev.insert(1, "-DHF_ENC_TRACE")
     host = ["g++", *common, *inc, "-c", SOURCES[1], "-o", objs[1]]
     link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     for cmd in (dev, host, link):

@@ -280,6 +280,14 @@ __device__ __forceinline__ uint32_t enc_sum_lens(const uint32_t raw[ENC_SPT / 4]
 // streams gain a little as well.
 __device__ __forceinline__ uint32_t enc_slot(uint32_t w) { return w + (w >> 5); }
 constexpr int ENC_IMG_SLOTS = ENC_WINW + ENC_WINW / 32 + 4;
+// The slot of image word w as a pointer, in two instructions: left to itself
+// the compiler distributes the scaling over the sum and needs three.
+__device__ __forceinline__ uint32_t *enc_slot_ptr(uint32_t *stg, uint32_t w)
+{
+    uint32_t byte_off;
+    asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(byte_off) : "v"(w), "v"(w >> 5));
+    return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(stg) + byte_off);
+}
 
 __device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos,
                                             uint64_t code, uint32_t len, uint32_t wlo,
@@ -358,14 +366,49 @@ struct EncSinkFlat {
         const bool full = nb >= 32 && alive;
         nb &= 31u;
         if (full)
-            __hip_atomic_fetch_or(stg + enc_slot(w), (uint32_t)(acc >> nb), __ATOMIC_RELAXED,
+            __hip_atomic_fetch_or(enc_slot_ptr(stg, w), (uint32_t)(acc >> nb), __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         w += full ? 1 : 0;
     }
     __device__ __forceinline__ void finish()
     {
         if (nb && alive)
-            __hip_atomic_fetch_or(stg + enc_slot(w), (uint32_t)(acc << (32 - nb)),
+            __hip_atomic_fetch_or(enc_slot_ptr(stg, w), (uint32_t)(acc << (32 - nb)),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+// The same sink for merged groups of at most 31 bits.  The bit count of the
+// word being filled lives in the top five bits of a register and the table
+// supplies len | len << 27, so that one add advances it, wraps it and leaves
+// "word complete" in the carry; the low bits only collect the lengths
+// (at most 32 x 31, far from bit 27).
+struct EncSinkCarry {
+    uint32_t *stg;
+    uint32_t w;
+    uint32_t nbl; // nb << 27 | junk
+    uint64_t acc;
+    static constexpr bool alive = true;
+    __device__ __forceinline__ EncSinkCarry(uint32_t *s, uint32_t bitpos)
+        : stg(s), w(bitpos >> 5), nbl(bitpos << 27), acc(0)
+    {
+    }
+    __device__ __forceinline__ void append(uint32_t code, uint32_t y) // y = len | len << 27
+    {
+        acc = (acc << (y & 63u)) | code;
+        uint32_t next;
+        const bool full = __builtin_add_overflow(nbl, y, &next);
+        nbl = next;
+        if (full)
+            __hip_atomic_fetch_or(enc_slot_ptr(stg, w), (uint32_t)(acc >> (nbl >> 27)),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        w += full ? 1 : 0;
+    }
+    __device__ __forceinline__ void finish()
+    {
+        const uint32_t nb = nbl >> 27;
+        if (nb)
+            __hip_atomic_fetch_or(enc_slot_ptr(stg, w), (uint32_t)(acc << (32 - nb)),
                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
@@ -419,14 +462,15 @@ __device__ __forceinline__ uint32_t enc_pick(const uint32_t (&raw)[ENC_BATCH][EN
     return v;
 }
 
-template <int G, bool SPEC, bool FULL>
+template <int G, bool SPEC, bool FULL, bool CARRY>
 __device__ __forceinline__ bool enc_pack_thread(const uint32_t (&raw)[ENC_BATCH][ENC_SPT / 4],
                                                 uint32_t t, uint32_t vcnt, const uint2 *s_tab2,
                                                 uint32_t *stg, uint32_t bitpos)
 {
+    static_assert(!(CARRY && SPEC), "the carry sink needs groups of at most 31 bits");
     constexpr int LG = 4; // lookups per group = the four symbols of one input dword
     const uint2 *tab = s_tab2 + (threadIdx.x & (ENC_REPL - 1));
-    EncSinkFlat sink(stg, bitpos);
+    std::conditional_t<CARRY, EncSinkCarry, EncSinkFlat> sink(stg, bitpos);
     uint2 cur[LG], nxt[LG];
     auto fetch = [&](uint2 e[LG], int q) {
         const uint32_t dw = enc_pick(raw, t, q); // the four symbols of this group
@@ -449,7 +493,7 @@ __device__ __forceinline__ bool enc_pack_thread(const uint32_t (&raw)[ENC_BATCH]
                 code = (code << (cur[k + j].y & 31u)) | cur[k + j].x;
                 len += cur[k + j].y;
             }
-            if (SPEC)
+            if constexpr (SPEC)
                 sink.alive = sink.alive && len <= 32u;
             sink.append(code, len);
         }
@@ -462,16 +506,16 @@ __device__ __forceinline__ bool enc_pack_thread(const uint32_t (&raw)[ENC_BATCH]
     return sink.alive;
 }
 
-// Bits of the symbols that follow the tile, up to `need` (< 32) of them, so
-// that the tile's last stream word is complete.  Run by wave 0; `la_sym` is
-// the symbol at tile_end + lane, loaded together with the tile's own symbols
-// so that no global-memory latency sits between packing and copy-out.
-// Returns the number of bits that were available (capped once it reaches
-// `need`): fewer than `need` means the input ends inside this tile's last word.
-__device__ __forceinline__ uint32_t enc_lookahead(const EncParams &p, uint64_t tile_end,
-                                                  uint32_t la_sym, const uint2 *s_tab2,
-                                                  uint32_t *stg, uint32_t endbit, uint32_t need,
-                                                  uint32_t wlo, uint32_t whi)
+// The first 32 stream bits that follow a tile, left aligned in *s_la (ORed in:
+// the word starts as zero), and in *s_have how many of them exist (capped at
+// 32): what the tile needs to complete its last stream word.  They do not
+// depend on where the tile starts, so a wave that would otherwise idle
+// computes them while wave 0 is looking back.  `la_sym` is the symbol at
+// tile_end + lane, loaded together with the tile's own symbols so that no
+// global-memory latency is added here.
+__device__ __forceinline__ void enc_lookahead_bits(const EncParams &p, uint64_t tile_end,
+                                                   uint32_t la_sym, const uint2 *s_tab2,
+                                                   uint32_t *s_la, uint32_t *s_have)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t idx = tile_end + lane;
@@ -480,31 +524,43 @@ __device__ __forceinline__ uint32_t enc_lookahead(const EncParams &p, uint64_t t
     const uint32_t len = e2x.y & 63u;
     if (__builtin_expect((e2x.y & ENC_LONG_FLAG) != 0, 0))
         code = p.tab[la_sym] >> 6;
+    auto contribute = [&](uint64_t c, uint32_t l, uint32_t off) { // off < 32, l > 0
+        const int sh = 32 - (int)off - (int)l;
+        const uint32_t part = sh >= 0 ? (uint32_t)(c << sh) : (uint32_t)(c >> -sh);
+        __hip_atomic_fetch_or(s_la, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     const uint32_t incl = wave_incl_scan(len);
     const uint32_t off = incl - len;
-    if (len && off < need)
-        enc_or_bits(stg, endbit + off, code, len, wlo, whi, endbit + need);
+    if (len && off < 32u)
+        contribute(code, len, off);
     uint32_t have = __shfl(incl, 63, 64);
-    if (have < need && tile_end + 64 < p.n) {
+    if (have < 32u && tile_end + 64 < p.n) {
         // only reachable when the data holds symbols whose code length is 0
         if (lane == 0) {
-            for (uint64_t i = tile_end + 64; i < p.n && have < need; ++i) {
+            for (uint64_t i = tile_end + 64; i < p.n && have < 32u; ++i) {
                 const uint64_t e2 = p.tab[p.in[i]];
                 const uint32_t l2 = (uint32_t)e2 & 63u;
                 if (l2)
-                    enc_or_bits(stg, endbit + have, e2 >> 6, l2, wlo, whi, endbit + need);
+                    contribute(e2 >> 6, l2, have);
                 have += l2;
             }
         }
         have = __shfl(have, 0, 64);
     }
-    return have;
+    if (lane == 0)
+        *s_have = min(have, 32u);
 }
 
+// CARRY: the length word becomes len | len << 27 (see EncSinkCarry).
+template <bool CARRY>
 __device__ __forceinline__ void enc_stage_table(const EncParams &p, uint2 *s_tab2, uint8_t *s_len)
 {
-    for (uint32_t i = threadIdx.x; i < 256 * ENC_REPL; i += ENC_THREADS)
-        s_tab2[i] = p.tab2[i / ENC_REPL];
+    for (uint32_t i = threadIdx.x; i < 256 * ENC_REPL; i += ENC_THREADS) {
+        uint2 e = p.tab2[i / ENC_REPL];
+        if (CARRY)
+            e.y |= e.y << 27;
+        s_tab2[i] = e;
+    }
     if (threadIdx.x < 64)
         reinterpret_cast<uint32_t *>(s_len)[threadIdx.x] =
             reinterpret_cast<const uint32_t *>(p.len8)[threadIdx.x];
@@ -597,17 +653,25 @@ __global__ __launch_bounds__(256) void enc_scan_tiles_kernel(uint64_t *tile_off,
 // other data is handed between workgroups.  Tiles are numbered by a ticket
 // taken at workgroup start, so every predecessor of a waiting tile belongs to
 // a workgroup that is already running; waits are bounded by a wall clock.
-__device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, uint64_t &excl)
+__device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, uint64_t &excl,
+                                             uint64_t *dbg)
 {
     const uint32_t lane = threadIdx.x & 63u;
     uint64_t sum = 0;
     int64_t j = (int64_t)tile - 1;
     const uint64_t t_start = wall_clock64();
+    uint32_t polls = 0, steps = 0;
     while (true) {
         const int64_t idx = j - (int64_t)lane;
         unsigned long long d;
         uint32_t spins = 0;
+        ++steps;
+        // One read at a time: a descriptor read crosses the fabric (about
+        // 1.4 us under load) and the descriptors of all running workgroups
+        // share a few lines, so keeping several reads in flight, or reading a
+        // wider window, slows every workgroup's reads down (both measured).
         while (true) {
+            ++polls;
             d = idx >= 0 ? __hip_atomic_load(p.desc + idx, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT)
                          : DESC_INCL; // virtual tile -1: inclusive prefix 0
@@ -646,6 +710,8 @@ __device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, 
             break;
         j -= 64;
     }
+    if (dbg && lane == 0)
+        *dbg = polls | ((uint64_t)steps << 32);
     excl = sum;
     return true;
 }
@@ -653,25 +719,25 @@ __device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, 
 // Second half of an image pass: complete the tile's last word from the
 // symbols that follow it (last pass only) and copy the pass's words out with
 // coalesced byte-swapped 16-byte stores, clearing the image on the way.
-__device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *stg, uint32_t *s_ctl,
-                                                const uint2 *s_tab, uint32_t la_sym,
-                                                uint64_t tile_end, uint64_t E, uint64_t gbase,
+__device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *stg,
+                                                uint32_t la_bits, uint32_t la_have,
+                                                uint64_t E, uint64_t gbase,
                                                 uint64_t g0, uint64_t g1, uint32_t endbit,
-                                                uint32_t need, uint32_t nwords, uint32_t wlo)
+                                                uint32_t need, uint32_t nwords, uint32_t wlo,
+                                                bool reuse)
 {
     const uint32_t whi = wlo + ENC_WINW;
     const bool last_pass = nwords - 1 < whi;
-    if (threadIdx.x < 64 && last_pass) {
-        const uint32_t have =
-            need ? enc_lookahead(p, tile_end, la_sym, s_tab, stg, endbit, need, wlo, whi) : 0u;
-        if (threadIdx.x == 0)
-            s_ctl[1] = have;
-    }
+    // the word that holds the tile's last bit is completed by the first `need`
+    // bits of what follows the tile
+    if (threadIdx.x == 0 && last_pass && need)
+        __hip_atomic_fetch_or(stg + enc_slot((endbit >> 5) - wlo), la_bits >> (32u - need),
+                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     // the stream ends inside this tile's last word when fewer than `need`
     // bits follow the tile: only its leading bytes exist then
     const uint64_t limit =
-        (need && last_pass && s_ctl[1] < need) ? (E + s_ctl[1] + 7) >> 3 : ~0ull;
+        (need && last_pass && la_have < need) ? (E + la_have + 7) >> 3 : ~0ull;
     const uint64_t ga = max(g0, gbase + wlo);
     const uint64_t gb = min(g1, gbase + whi);
     // 16-byte units [ua, ub) of the stream intersect [ga, gb); the sweep starts
@@ -715,7 +781,8 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
             }
         }
     }
-    __syncthreads(); // the next pass ORs into units that were just read and cleared
+    if (reuse)
+        __syncthreads(); // the next pass ORs into units that were just read and cleared
 }
 
 // A workgroup encodes a batch of ENC_BATCH consecutive tiles in two stages.
@@ -734,17 +801,43 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
 // at the end of the input, and unaligned inputs, with FULL = false so that the
 // hot instantiation carries no tail handling.  first_batch offsets the batch
 // index of such a follow-up launch.
-template <int G, bool SPEC, bool FULL>
+//
+// Built with -DHF_ENC_TRACE (HF_ENC_TRACE=1 python huffman_amd/build.py) and run
+// with the context option debug = 16, threads 0 and 448 of every workgroup
+// stamp the wall clock at the phase boundaries below into the unused tail of
+// the output buffer (40 x 8 bytes per batch); tools/trace_enc.py prints the
+// resulting timeline (the stream itself must end before that tail, or it is
+// overwritten: a diagnostic build, not for production use).
+#ifdef HF_ENC_TRACE
+#define ENC_TRACE(i)                                                                          \
+    do {                                                                                      \
+        if (trp)                                                                              \
+            trp[(i)] = wall_clock64();                                                        \
+    } while (0)
+#define ENC_TRACE_TILE(t, i) ENC_TRACE(7 + 3 * (t) + (i))
+constexpr uint64_t ENC_TRACE_BYTES = 320; // per batch
+#else
+#define ENC_TRACE(i)                                                                          \
+    do {                                                                                      \
+    } while (0)
+#define ENC_TRACE_TILE(t, i) ENC_TRACE(0)
+#endif
+template <int G, bool SPEC, bool FULL, bool CARRY>
 __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(EncParams p)
 {
+#ifdef HF_ENC_TRACE
+    const uint64_t trace_t0 = wall_clock64();
+    uint64_t *trp = nullptr;
+#endif
     const bool CHAINED = p.desc != nullptr; // else: tile offsets come from the scan kernel
-    __shared__ __align__(16) uint32_t stg[ENC_IMG_SLOTS];
+    __shared__ __align__(16) uint32_t stg2[2][ENC_IMG_SLOTS];
     __shared__ uint2 s_tab[256 * ENC_REPL];
     __shared__ __align__(16) uint8_t s_len[256];
     __shared__ uint32_t s_toff[ENC_BATCH][ENC_THREADS + 1];
     __shared__ uint32_t s_wave[ENC_BATCH][ENC_WAVES];
     __shared__ uint64_t s_start;
     __shared__ uint32_t s_ctl[2];
+    __shared__ uint32_t s_la[ENC_BATCH], s_have[ENC_BATCH]; // look-ahead bits per tile
     __shared__ uint32_t s_batch;
 
     // the ticket first: its round trip overlaps with the staging of the tables
@@ -752,11 +845,22 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
         if (threadIdx.x == 0)
             s_batch = p.first_batch + ((p.debug & 4u) ? blockIdx.x : atomicAdd(p.ticket, 1u));
     }
-    enc_stage_table(p, s_tab, s_len);
-    for (uint32_t i = threadIdx.x; i < sizeof(stg) / 16; i += ENC_THREADS)
-        reinterpret_cast<uint4 *>(stg)[i] = make_uint4(0, 0, 0, 0);
+    enc_stage_table<CARRY>(p, s_tab, s_len);
+    if (threadIdx.x < ENC_BATCH)
+        s_la[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < sizeof(stg2) / 16; i += ENC_THREADS)
+        reinterpret_cast<uint4 *>(&stg2[0][0])[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t batch = CHAINED ? s_batch : p.first_batch + blockIdx.x;
+#ifdef HF_ENC_TRACE
+    if ((p.debug & 16u) && (threadIdx.x == 0 || threadIdx.x == 448)) {
+        const uint64_t tail = ((uint64_t)p.n_tiles / ENC_BATCH + 2) * ENC_TRACE_BYTES;
+        trp = reinterpret_cast<uint64_t *>(p.out + ((p.out_cap - tail) & ~15ull)) +
+              (uint64_t)batch * 40 + (threadIdx.x ? 20 : 0);
+        trp[0] = trace_t0;
+    }
+#endif
+    ENC_TRACE(1);
     const uint32_t tile0 = batch * ENC_BATCH;
     if (tile0 >= p.n_tiles)
         return;
@@ -766,15 +870,18 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
     // ---- stage A
     uint32_t raw[ENC_BATCH][ENC_SPT / 4];
     uint32_t vcnt[ENC_BATCH];
-    uint32_t la_sym[ENC_BATCH]; // wave 0: the symbol `lane` places behind each tile
+    uint32_t la_sym = 0; // wave t + 1: the symbol `lane` places behind tile t
+    uint64_t la_end = 0; //             and where that tile ends
 #pragma unroll
     for (int t = 0; t < ENC_BATCH; ++t) {
         const uint64_t base = (uint64_t)(tile0 + t) * ENC_TILE;
         const uint64_t left = base < p.n ? p.n - base : 0;
         const uint32_t nsym = left < ENC_TILE ? (uint32_t)left : ENC_TILE;
-        la_sym[t] = 0;
-        if (threadIdx.x < 64 && base + nsym + threadIdx.x < p.n)
-            la_sym[t] = p.in[base + nsym + threadIdx.x];
+        if (wv == (uint32_t)t + 1) {
+            la_end = base + nsym;
+            if (la_end + lane < p.n)
+                la_sym = p.in[la_end + lane];
+        }
         if (FULL)
             __builtin_assume(nsym == ENC_TILE);
         vcnt[t] = FULL ? (uint32_t)ENC_SPT : (nsym > t0 ? min(nsym - t0, (uint32_t)ENC_SPT) : 0u);
@@ -789,7 +896,9 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
         if (lane == 63)
             s_wave[t][wv] = incl[t];
     }
+    ENC_TRACE(2);
     __syncthreads();
+    ENC_TRACE(3);
     uint32_t batch_bits = 0;
 #pragma unroll
     for (int t = 0; t < ENC_BATCH; ++t) {
@@ -806,6 +915,10 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
         batch_bits += tot;
     }
 
+    ENC_TRACE(4);
+    // waves 1.. complete the tiles' last words in advance, one tile each
+    if (wv >= 1 && wv <= (uint32_t)ENC_BATCH && tile0 + wv - 1 < p.n_tiles)
+        enc_lookahead_bits(p, la_end, la_sym, s_tab, &s_la[wv - 1], &s_have[wv - 1]);
     // start bit of the batch in the stream (lead bits included)
     if (CHAINED) {
         if (threadIdx.x < 64) {
@@ -820,7 +933,13 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
                     __hip_atomic_store(p.desc + batch, DESC_AGG | (unsigned long long)batch_bits,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!(p.debug & 8u))
-                    ok = enc_lookback(p, batch, excl);
+                    {
+#ifdef HF_ENC_TRACE
+                    ok = enc_lookback(p, batch, excl, trp ? trp + 19 : nullptr);
+#else
+                    ok = enc_lookback(p, batch, excl, nullptr);
+#endif
+                }
                 if (ok && threadIdx.x == 0)
                     __hip_atomic_store(p.desc + batch,
                                        DESC_INCL | (unsigned long long)(excl + batch_bits),
@@ -837,7 +956,9 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
             s_ctl[0] = 1u;
         }
     }
+    ENC_TRACE(5);
     __syncthreads();
+    ENC_TRACE(6);
     if (!s_ctl[0])
         return; // a wait expired: the host reports HF_ERR_INTERNAL
     uint64_t S = s_start;
@@ -854,7 +975,12 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
         // the table is read again here on purpose: without this fence the
         // compiler keeps all of stage A's lookups alive (in scratch) instead
         asm volatile("" ::: "memory");
-        const uint32_t vc = vcnt[0], la = la_sym[0];
+        const uint32_t vc = vcnt[0];
+        // consecutive tiles alternate between two images: a wave that has
+        // copied its share of tile t out packs tile t + 1 straight away, and
+        // the barrier after that packing also tells that the image of tile t
+        // is clear again for tile t + 2
+        uint32_t *stg = stg2[t & 1u];
         const uint64_t base = (uint64_t)tile * ENC_TILE;
         const uint64_t left = p.n - base;
         const uint64_t tile_end = base + (left < ENC_TILE ? left : (uint64_t)ENC_TILE);
@@ -895,25 +1021,26 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
                 // common case, straight-line: the whole tile fits one image pass
                 if (my_bits && !(p.debug & 2u)) {
                     const bool done =
-                        enc_pack_thread<G, SPEC, FULL>(raw, 0, vc, s_tab, stg, s_lo + toff);
+                        enc_pack_thread<G, SPEC, FULL, CARRY>(raw, 0, vc, s_tab, stg, s_lo + toff);
                     if (SPEC && __builtin_expect(!done, 0)) // rare by the host's choice of G
                         enc_pack_thread_rolled(p, base + t0, vc, stg, s_lo + toff, my_bits, 0);
                 }
-                enc_finish_pass(p, stg, s_ctl, s_tab, la, tile_end, E, gbase, g0, g1, endbit, need,
-                                nwords, 0);
+                ENC_TRACE_TILE(t, 0); // packed
+                enc_finish_pass(p, stg, s_la[t], s_have[t], E, gbase, g0, g1, endbit, need, nwords,
+                                0, false);
             } else {
                 for (uint32_t wlo = 0; wlo < nwords; wlo += ENC_WINW) {
                     enc_pack_thread_rolled(p, base + t0, vc, stg, s_lo + toff, my_bits, wlo);
-                    enc_finish_pass(p, stg, s_ctl, s_tab, la, tile_end, E, gbase, g0, g1, endbit,
-                                    need, nwords, wlo);
+                    enc_finish_pass(p, stg, s_la[t], s_have[t], E, gbase, g0, g1, endbit, need,
+                                    nwords, wlo, true);
                 }
             }
         }
+        ENC_TRACE_TILE(t, 2); // copied out
         S = E;
 #pragma unroll
         for (int u = 0; u + 1 < ENC_BATCH; ++u) {
             vcnt[u] = vcnt[u + 1];
-            la_sym[u] = la_sym[u + 1];
 #pragma unroll
             for (int q = 0; q < ENC_SPT / 4; ++q)
                 raw[u][q] = raw[u + 1][q];
@@ -2304,6 +2431,10 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     p.n_tiles = n_tiles;
     p.timeout_ticks = (uint64_t)ctx->timeout_ms * 100000ull;
     p.debug = (uint32_t)ctx->debug & 31u;
+#ifdef HF_ENC_TRACE
+    if (out_cap < ((uint64_t)n_tiles / ENC_BATCH + 3) * ENC_TRACE_BYTES)
+#endif
+        p.debug &= ~16u; // the phase trace overwrites the tail of the output buffer
 
     const size_t need = ((size_t)n_tiles + 4) * sizeof(uint64_t);
     int rc = ensure_scratch(ctx, need);
@@ -2312,6 +2443,8 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     // codes merged per append, and whether the table flags codes too long for that
     const int g = model->enc_group;
     const bool flagged = model->enc_spec;
+    // every merged group stays below 32 bits: the carry sink applies
+    const bool carry = !flagged && g > 1 && (uint32_t)g * model->maxlen <= 31u;
     const uint32_t n_batches = (n_tiles + ENC_BATCH - 1) / ENC_BATCH;
     // batches whose tiles are all complete run the lean instantiation; the
     // ragged last batch (and everything, if the input is unaligned) the general one
@@ -2336,9 +2469,13 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
             continue;
         p.first_batch = lean ? 0u : n_lean;
         void (*kern)(EncParams) = nullptr;
-#define HF_PICK(G)                                                                           \
-    (flagged ? (lean ? enc_pack_kernel<G, true, true> : enc_pack_kernel<G, true, false>)     \
-             : (lean ? enc_pack_kernel<G, false, true> : enc_pack_kernel<G, false, false>))
+#define HF_PICK(G)                                                                            \
+    (flagged ? (lean ? enc_pack_kernel<G, true, true, false>                                  \
+                     : enc_pack_kernel<G, true, false, false>)                                \
+             : carry ? (lean ? enc_pack_kernel<G, false, true, (G > 1)>                       \
+                             : enc_pack_kernel<G, false, false, (G > 1)>)                     \
+                     : (lean ? enc_pack_kernel<G, false, true, false>                         \
+                             : enc_pack_kernel<G, false, false, false>))
         kern = g == 4 ? HF_PICK(4) : (g == 2 ? HF_PICK(2) : HF_PICK(1));
 #undef HF_PICK
         hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), 0, ctx->stream, p);
