@@ -41,8 +41,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform", "geometric", "testfile"])
     ap.add_argument("--gib", type=float, default=None, help="GiB per GPU (default 1)")
     ap.add_argument("--chunk-syms", type=int, default=hd.DEFAULT_CHUNK_SYMS)

@@ -1,9 +1,14 @@
 """Times the three kernels back to back (HIP events, many repetitions) for A/B
-comparisons of kernel changes: python tools/time_kernels.py [kind] [mib] [reps]"""
+comparisons of kernel changes: python tools/time_kernels.py [kind] [mib] [reps]
+(HF_TOOLS_LIB=path/to/other/libhfgpu.so times another build on the same box)"""
+import os
 import sys
 import numpy as np
 import torch
 sys.path.insert(0, ".")
+import huffman_amd._lib as _lib
+if os.environ.get("HF_TOOLS_LIB"):  # A/B runs: another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["HF_TOOLS_LIB"])
 from huffman_amd import device as hd, synth
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
@@ -38,6 +43,7 @@ def timed(fn):
     return ts[len(ts) // 2], ts[0]
 
 
+timed(lambda: hd.encode_async(data, model, bufs))  # clocks settle during the first passes
 h = timed(lambda: hd.histogram_async(data, d_hist))
 e = timed(lambda: hd.encode_async(data, model, bufs))
 d = timed(lambda: hd.decode_async(bufs.data, nbytes, model, n, 64, bufs.chunk_bits, bufs.seg_off, out, dres))
