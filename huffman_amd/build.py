@@ -71,6 +71,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         dev.insert(1, "-Rpass-analysis=kernel-resource-usage")
     if os.environ.get("HF_ENC_TRACE") == "1":  # phase stamps in the encode kernel (tools/trace_enc.py)
         dev.insert(1, "-DHF_ENC_TRACE")
+    if os.environ.get("HF_DEC_TRACE") == "1":  # the same for the decode kernel (tools/trace_dec.py)
+        dev.insert(1, "-DHF_DEC_TRACE")
     host = ["g++", *common, *inc, "-c", SOURCES[1], "-o", objs[1]]
     link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     for cmd in (dev, host, link):

@@ -1086,6 +1086,7 @@ struct DecParams {
     uint32_t istg_words;
     uint32_t in_aligned16;
     uint32_t out_aligned16;
+    uint64_t *trace; // HF_DEC_TRACE builds: 16 stamps per segment, or null
 };
 
 // Big-endian 32-bit word `w` of the compressed buffer; bytes past the end are 0.
@@ -1389,6 +1390,21 @@ __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uin
 // its dependent table lookups, i.e. by the number of chunks in flight.
 // Lanes whose chunk is ragged (end of the stream) and segments too dense for
 // the image take a rolled loop that stores bytes straight to global memory.
+// Built with -DHF_DEC_TRACE (HF_DEC_TRACE=1 python huffman_amd/build.py) and
+// given a buffer through the context option "dec_trace", threads 0 and 192 of
+// every work-group stamp the wall clock at the phase boundaries of the decode
+// kernel (8 stamps each per segment); tools/trace_dec.py prints the timeline.
+#ifdef HF_DEC_TRACE
+#define DEC_TRACE(i)                                                                          \
+    do {                                                                                      \
+        if (trp)                                                                              \
+            trp[(i)] = wall_clock64();                                                        \
+    } while (0)
+#else
+#define DEC_TRACE(i)                                                                          \
+    do {                                                                                      \
+    } while (0)
+#endif
 template <int CS, int K, bool ESC, bool SWZ, bool SPEC>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
 {
@@ -1401,30 +1417,89 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     uint32_t *s_wave = img + p.istg_words;
 
     const uint64_t seg = blockIdx.x;
+#ifdef HF_DEC_TRACE
+    uint64_t *trp = (p.trace && (threadIdx.x == 0 || threadIdx.x == 192))
+                        ? p.trace + seg * 16 + (threadIdx.x ? 8 : 0)
+                        : nullptr;
+#endif
+    DEC_TRACE(0);
+    // The segment's span of the stream is known from the segment offsets
+    // alone (this one's and the next one's), so its first 16 KiB are requested
+    // before anything else: one memory latency covers them, the gap array and
+    // the table, instead of two in a row.
     const uint64_t c = seg * HF_SEG_CHUNKS + threadIdx.x;
     const bool valid = c < p.n_chunks;
     const uint32_t cb = valid ? p.chunk_bits[c] : 0u;
+    const uint4 *lut16 = reinterpret_cast<const uint4 *>(p.lut);
+    const uint4 lut0 = threadIdx.x < lut_bytes / 16 ? lut16[threadIdx.x] : make_uint4(0, 0, 0, 0);
+    // (straight-line on purpose: a load behind a branch is waited for at once)
+    const uint64_t last_seg = (p.n_chunks - 1) / HF_SEG_CHUNKS;
+    const uint64_t so0 = p.seg_off[seg], so1 = p.seg_off[min(seg + 1, last_seg)];
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t seg_start = so0 - p.bit_base;
+    const uint64_t ubase = seg_start >> 7;
+    const uint32_t s_lo = (uint32_t)(seg_start & 127u);
+    constexpr uint32_t IMG_CAP = HF_SEG_CHUNKS * CS / 4 + 16; // words
+    constexpr int EARLY = 4;                                  // 16-byte units per lane
+    const uint64_t whole = p.in_bytes >> 4;
+    const uint4 *in16 = reinterpret_cast<const uint4 *>(p.in);
+    uint32_t nunits_e = 0;
+    if (seg < last_seg && p.in_aligned16 && so1 - so0 <= (uint64_t)IMG_CAP * 32u) {
+        nunits_e = (uint32_t)((s_lo + (so1 - so0) + 127u) / 128u) + 1u;
+        if (nunits_e * 4u > IMG_CAP || ubase + nunits_e > whole)
+            nunits_e = 0;
+    }
+    uint4 st[EARLY];
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.lut);
+        // unconditional: without a span to fetch, the loads re-read the table
+        const uint4 *from = nunits_e ? in16 + ubase : lut16;
+        const uint32_t top = nunits_e ? nunits_e - 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < EARLY; ++k)
+            st[k] = from[min(threadIdx.x + k * DEC_THREADS, top)];
+    }
+    __builtin_amdgcn_sched_barrier(0); // loads return in order: the small ones were issued first
+    {
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = threadIdx.x; i < lut_bytes / 16; i += DEC_THREADS)
-            dst[i] = src[i];
+        if (threadIdx.x < lut_bytes / 16)
+            dst[threadIdx.x] = lut0;
+        for (uint32_t i = threadIdx.x + DEC_THREADS; i < lut_bytes / 16; i += DEC_THREADS)
+            dst[i] = lut16[i];
     }
     uint32_t total;
     const uint32_t excl = block_excl_scan256(cb, s_wave, total);
-    const uint64_t seg_start = p.seg_off[seg] - p.bit_base;
-    const uint64_t ubase = seg_start >> 7;
-    const uint32_t s_lo = (uint32_t)(seg_start & 127u);
+    DEC_TRACE(1); // gap array and table in, chunk offsets scanned
     const uint32_t nunits = (s_lo + total + 127u) / 128u + 1u; // +1: readers run ahead
-    const bool use_lds = nunits * 4u <= (uint32_t)(HF_SEG_CHUNKS * CS / 4 + 16) && p.in_aligned16;
+    const bool use_lds = nunits * 4u <= IMG_CAP && p.in_aligned16;
     if (use_lds) {
-        const uint64_t whole = p.in_bytes >> 4;
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.in);
-        for (uint32_t i = threadIdx.x; i < nunits; i += DEC_THREADS) {
+        auto put = [&](uint32_t i, uint4 v) {
+            if (SWZ) { // word w of the image lives in slot w + w / 32 (see SwzWords)
+                uint32_t *dst = img + 4 * i + ((4 * i) >> 5);
+                dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+            } else {
+                reinterpret_cast<uint4 *>(img)[i] = v;
+            }
+        };
+        // (a gap array whose chunk lengths exceed the segment's span is
+        // inconsistent: everything is then fetched here, as for the last segment)
+        const bool early_ok = nunits <= nunits_e;
+        if (early_ok) {
+#pragma unroll
+            for (int k = 0; k < EARLY; ++k) {
+                const uint32_t i = threadIdx.x + k * DEC_THREADS;
+                if (i < nunits) {
+                    uint4 v = st[k];
+                    v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
+                    put(i, v);
+                }
+            }
+        }
+        for (uint32_t i = threadIdx.x + (early_ok ? EARLY * DEC_THREADS : 0); i < nunits;
+             i += DEC_THREADS) {
             const uint64_t u = ubase + i;
             uint4 v;
             if (u < whole) {
-                v = src[u];
+                v = in16[u];
                 v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
             } else {
                 v.x = dec_load_word(p.in, p.in_bytes, u * 4 + 0);
@@ -1432,15 +1507,12 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                 v.z = dec_load_word(p.in, p.in_bytes, u * 4 + 2);
                 v.w = dec_load_word(p.in, p.in_bytes, u * 4 + 3);
             }
-            if (SWZ) { // word w of the image lives in slot w + w / 32 (see SwzWords)
-                uint32_t *dst = img + 4 * i + ((4 * i) >> 5);
-                dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
-            } else {
-                reinterpret_cast<uint4 *>(img)[i] = v;
-            }
+            put(i, v);
         }
     }
+    DEC_TRACE(2); // stream image staged (this wave's share)
     __syncthreads();
+    DEC_TRACE(3);
 
     const uint64_t sym0 = c * CS;
     const uint32_t cnt = valid ? (uint32_t)min((uint64_t)CS, p.n_out - sym0) : 0u;
@@ -1517,6 +1589,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             p.out[sym0 + i] = (uint8_t)dec_symbol<GlobalWords, true>(br, s_lut, shift, p, bad);
         }
     }
+    DEC_TRACE(4); // decoded
     if (bad && !dirty) // a dirty lane's symbols (and errors) are not real: it decodes again below
         atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
     __syncthreads(); // every lane is done with the compressed image: reuse it for the output
@@ -1526,7 +1599,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
         for (int i = 0; i < CS / 4; ++i)
             orow[i] = outw[i];
     }
+    DEC_TRACE(5); // output rows written
     __syncthreads();
+    DEC_TRACE(6);
     if (!use_lds)
         return;
     // coalesced copy-out of the whole chunks of the segment
@@ -1550,6 +1625,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                 p.out[obase + o + i] = (uint8_t)(vv[i >> 2] >> (8 * (i & 3)));
         }
     }
+    DEC_TRACE(7); // copied out
     if (SPEC) {
         __syncthreads(); // the chunk's (wrong) bytes from the image have been stored
         if (dirty) {
@@ -1944,6 +2020,7 @@ struct hf_ctx {
     int hist_grid = 0;
     int timeout_ms = 2000;
     int debug = 0;
+    uint64_t *dec_trace = nullptr; // device buffer for the decode kernel's phase stamps
     // device blocks of destroyed models, kept for the next hf_model_create: a
     // codec that builds a model per stream would otherwise pay hipMalloc/hipFree each time
     std::vector<std::pair<void *, size_t>> blob_cache;
@@ -2204,6 +2281,8 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
         ctx->hist_grid = (int)value;
     else if (!std::strcmp(name, "timeout_ms") && value > 0 && value <= 60000)
         ctx->timeout_ms = (int)value;
+    else if (!std::strcmp(name, "dec_trace")) // device address, 128 bytes per segment; 0 = off
+        ctx->dec_trace = reinterpret_cast<uint64_t *>((uintptr_t)value);
     else if (!std::strcmp(name, "debug") && value >= 0 && value < 512)
         ctx->debug = (int)value;
     else
@@ -2561,6 +2640,7 @@ static int fill_dec_params(hf_ctx *ctx, const hf_model *model, const uint8_t *d_
     p->klens = model->d_klens;
     p->m = model->m;
     p->out_aligned16 = ((uintptr_t)d_out & 15) == 0;
+    p->trace = ctx->dec_trace;
     p->in_aligned16 = ((uintptr_t)d_in & 15) == 0;
     return HF_OK;
 }
