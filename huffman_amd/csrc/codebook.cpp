@@ -273,6 +273,19 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
             }
             lut->has_escape = lut->has_escape || (e & 0x8000u);
             lut->pool[job.base + i] = e;
+            // a direct entry repeats for every following slot that ends before
+            // the next key: fill the run instead of deriving each slot
+            if (!(e & 0x8000u)) {
+                const uint32_t dc = job.width - sig;
+                uint64_t part_end = (uint64_t)1 << sig;
+                if (plo + 1 < (int64_t)m)
+                    part_end = std::min(part_end, (keys[plo + 1] >> rem) - (job.prefix << sig));
+                const uint64_t i_end = part_end << dc;
+                for (uint64_t q = i + 1; q < i_end; ++q)
+                    lut->pool[job.base + q] = e;
+                if (i_end > i + 1)
+                    i = (uint32_t)(i_end - 1);
+            }
         }
     }
     return HF_OK;
@@ -298,7 +311,7 @@ uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t
     double kraft = 0;
     int present[64], np = 0;
     for (uint64_t i = 0; i < m; ++i) {
-        const double w = std::ldexp(1.0, -(int)klens[i]);
+        const double w = klens[i] < 64 ? 1.0 / (double)((uint64_t)1 << klens[i]) : std::ldexp(1.0, -64);
         if (d[klens[i]] == 0)
             present[np++] = klens[i];
         d[klens[i]] += w;
@@ -310,17 +323,27 @@ uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t
     double c[66] = {0};
     c[0] = 1.0;
     double over[2] = {1.0, 1.0};
+    int lo = 0, hi = 0; // sums that can occur so far (below the overflow bin)
+    int minlen = 64, maxl = 0;
+    for (int q = 0; q < np; ++q)
+        minlen = std::min(minlen, present[q]), maxl = std::max(maxl, present[q]);
     for (uint32_t i = 1; i <= 16; ++i) {
         double nc[66] = {0};
-        for (int a = 0; a <= 65; ++a) {
+        nc[65] = c[65];
+        for (int a = lo; a <= hi; ++a) {
             if (c[a] == 0)
                 continue;
             for (int q = 0; q < np; ++q)
                 nc[std::min(a + present[q], 65)] += c[a] * d[present[q]];
         }
         std::memcpy(c, nc, sizeof(c));
-        if (i == 8)
+        lo = std::min(lo + minlen, 64), hi = std::min(hi + maxl, 64);
+        if (i == 8) {
             over[1] = c[65];
+            // 16 codes overflow at least as often as 8: nothing left to find
+            if (1.0 - std::pow(1.0 - over[1], 8.0) > 1e-7)
+                return 0;
+        }
         if (i == 16)
             over[0] = c[65];
     }
@@ -343,7 +366,7 @@ int pick_merge_width(const uint64_t lens[256], bool *speculative)
     for (int s = 0; s < 256; ++s) {
         if (lens[s] == 0 || lens[s] > 64)
             continue;
-        const double w = std::ldexp(1.0, -(int)lens[s]);
+        const double w = lens[s] < 64 ? 1.0 / (double)((uint64_t)1 << lens[s]) : std::ldexp(1.0, -64);
         d[lens[s]] += w;
         kraft += w;
         maxlen = std::max(maxlen, lens[s]);
@@ -351,8 +374,12 @@ int pick_merge_width(const uint64_t lens[256], bool *speculative)
     *speculative = maxlen > 32;
     if (kraft <= 0)
         return 1;
-    for (double &x : d)
-        x /= kraft;
+    int present[64], np = 0;
+    for (int l = 1; l <= 64; ++l) {
+        d[l] /= kraft;
+        if (d[l] != 0)
+            present[np++] = l;
+    }
     for (int g : {4, 2}) {
         if (maxlen * g <= 32) {
             *speculative = false;
@@ -363,10 +390,12 @@ int pick_merge_width(const uint64_t lens[256], bool *speculative)
         c[0] = 1.0;
         for (int i = 0; i < g; ++i) {
             double nc[34] = {0};
-            for (int a = 0; a <= 33; ++a)
-                for (int l = 1; l <= 64; ++l)
-                    if (c[a] != 0 && d[l] != 0)
-                        nc[std::min(a + l, 33)] += c[a] * d[l];
+            for (int a = 0; a <= 33; ++a) {
+                if (c[a] == 0)
+                    continue;
+                for (int q = 0; q < np; ++q)
+                    nc[std::min(a + present[q], 33)] += c[a] * d[present[q]];
+            }
             std::memcpy(c, nc, sizeof(c));
         }
         const double p_tile = 1.0 - std::pow(1.0 - c[33], 32.0 / g); // a lane's 32 symbols

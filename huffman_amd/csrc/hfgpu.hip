@@ -2023,7 +2023,23 @@ struct hf_ctx {
     uint64_t *dec_trace = nullptr; // device buffer for the decode kernel's phase stamps
     // device blocks of destroyed models, kept for the next hf_model_create: a
     // codec that builds a model per stream would otherwise pay hipMalloc/hipFree each time
-    std::vector<std::pair<void *, size_t>> blob_cache;
+    struct Blob {
+        void *d;
+        size_t bytes;
+        hipStream_t last_stream; // kernels of the model that owned it ran there
+    };
+    std::vector<Blob> blob_cache;
+    // pinned staging of the table uploads, used in turn: the upload is an
+    // asynchronous copy on the context's stream, `done` tells when a buffer
+    // may be filled again
+    struct Pinned {
+        void *h = nullptr;
+        size_t bytes = 0;
+        hipEvent_t done = nullptr;
+        bool used = false;
+    };
+    Pinned pinned[4];
+    unsigned pinned_next = 0;
     void *arena = nullptr; // device staging of the *_host entry points (grow only)
     size_t arena_bytes = 0;
 };
@@ -2050,6 +2066,9 @@ struct hf_model {
     bool lut_escapes = false; // the decode table holds entries with the escape bit
     bool regular_chunks = false; // 64 symbols are expected to differ by < 8 bits in length
     uint32_t dec_spec_k = 0; // 16 or 8: codes per 64-bit window the decoder may assume (else 0)
+    hipStream_t use_stream = nullptr; // the tables were uploaded on this stream ...
+    hipEvent_t ready = nullptr;       // ... and are complete once this event has passed
+    mutable bool foreign = false;     // kernels on other streams have used the tables
 };
 
 namespace {
@@ -2129,21 +2148,39 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     const size_t off_ksyms = off_keys + 256 * sizeof(uint64_t);
     const size_t off_klens = off_ksyms + 256;
     const size_t total = off_klens + 256;
-    std::vector<uint8_t> blob(total, 0);
+    HF_HIP(ctx, hipSetDevice(ctx->device));
+    hf_ctx::Pinned &ps = ctx->pinned[ctx->pinned_next++ % 4];
+    if (ps.used)
+        HF_HIP(ctx, hipEventSynchronize(ps.done)); // the copy that last read this buffer is over
+    if (ps.bytes < total) {
+        if (ps.h)
+            HF_HIP(ctx, hipHostFree(ps.h));
+        ps.h = nullptr, ps.bytes = 0;
+        HF_HIP(ctx, hipHostMalloc(&ps.h, align_up(total, 4096), hipHostMallocDefault));
+        ps.bytes = align_up(total, 4096);
+    }
+    if (!ps.done)
+        HF_HIP(ctx, hipEventCreateWithFlags(&ps.done, hipEventDisableTiming));
+    uint8_t *blob = static_cast<uint8_t *>(ps.h);
+    std::memset(blob, 0, total);
     if (enc_tab) {
-        std::memcpy(blob.data() + off_enc, enc_tab, 256 * sizeof(uint64_t));
-        std::memcpy(blob.data() + off_enc2, enc_tab2, 512 * sizeof(uint32_t));
+        std::memcpy(blob + off_enc, enc_tab, 256 * sizeof(uint64_t));
+        std::memcpy(blob + off_enc2, enc_tab2, 512 * sizeof(uint32_t));
         for (int i = 0; i < 256; ++i)
             blob[off_len8 + i] = (uint8_t)(enc_tab[i] & 63u);
     }
-    std::memcpy(blob.data() + off_lut, lut.pool.data(), lut.pool.size() * 2);
-    std::memcpy(blob.data() + off_keys, keys, m * sizeof(uint64_t));
-    std::memcpy(blob.data() + off_ksyms, syms, m);
-    std::memcpy(blob.data() + off_klens, klens, m);
+    std::memcpy(blob + off_lut, lut.pool.data(), lut.pool.size() * 2);
+    std::memcpy(blob + off_keys, keys, m * sizeof(uint64_t));
+    std::memcpy(blob + off_ksyms, syms, m);
+    std::memcpy(blob + off_klens, klens, m);
     for (size_t i = 0; i < ctx->blob_cache.size(); ++i) {
-        if (ctx->blob_cache[i].second >= total) {
-            mod->d_blob = ctx->blob_cache[i].first;
-            mod->blob_bytes = ctx->blob_cache[i].second;
+        if (ctx->blob_cache[i].bytes >= total) {
+            // kernels of the block's previous owner may still be running: on
+            // this stream the copy queues up behind them, another one is waited for
+            if (ctx->blob_cache[i].last_stream != ctx->stream)
+                HF_HIP(ctx, hipStreamSynchronize(ctx->blob_cache[i].last_stream));
+            mod->d_blob = ctx->blob_cache[i].d;
+            mod->blob_bytes = ctx->blob_cache[i].bytes;
             ctx->blob_cache.erase(ctx->blob_cache.begin() + (long)i);
             break;
         }
@@ -2152,7 +2189,11 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
         mod->blob_bytes = align_up(total, 4096);
         HF_HIP(ctx, hipMalloc(&mod->d_blob, mod->blob_bytes));
     }
-    HF_HIP(ctx, hipMemcpy(mod->d_blob, blob.data(), total, hipMemcpyHostToDevice));
+    HF_HIP(ctx, hipMemcpyAsync(mod->d_blob, blob, total, hipMemcpyHostToDevice, ctx->stream));
+    HF_HIP(ctx, hipEventRecord(ps.done, ctx->stream));
+    ps.used = true;
+    mod->use_stream = ctx->stream;
+    mod->ready = ps.done;
     uint8_t *b = static_cast<uint8_t *>(mod->d_blob);
     mod->d_enc = reinterpret_cast<uint64_t *>(b + off_enc);
     mod->d_enc2 = reinterpret_cast<uint2 *>(b + off_enc2);
@@ -2184,6 +2225,18 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
 bool valid_chunk_syms(uint32_t cs)
 {
     return cs == 64 || cs == 128 || cs == 256;
+}
+
+// Work that reads a model's tables must come after their upload: on the
+// stream that carried the upload that is the case already, any other stream
+// waits for the upload's event (and the model remembers the foreign use).
+int model_on_stream(hf_ctx *ctx, const hf_model *model)
+{
+    if (model->ready && ctx->stream != model->use_stream) {
+        HF_HIP(ctx, hipStreamWaitEvent(ctx->stream, model->ready, 0));
+        model->foreign = true;
+    }
+    return HF_OK;
 }
 
 } // namespace
@@ -2246,7 +2299,13 @@ int hf_ctx_destroy(hf_ctx *ctx)
     if (ctx->arena)
         (void)hipFree(ctx->arena);
     for (auto &b : ctx->blob_cache)
-        (void)hipFree(b.first);
+        (void)hipFree(b.d);
+    for (auto &ps : ctx->pinned) {
+        if (ps.h)
+            (void)hipHostFree(ps.h);
+        if (ps.done)
+            (void)hipEventDestroy(ps.done);
+    }
     if (ctx->d_result)
         (void)hipFree(ctx->d_result);
     delete ctx;
@@ -2433,11 +2492,17 @@ int hf_model_destroy(hf_model *model)
         return HF_OK;
     if (model->d_blob) {
         (void)hipSetDevice(model->ctx->device);
-        (void)hipStreamSynchronize(model->ctx->stream); // no kernel reads the tables any more
-        if (model->ctx->blob_cache.size() < 4)
-            model->ctx->blob_cache.emplace_back(model->d_blob, model->blob_bytes);
-        else
+        // Kernels that read the tables may still be queued.  The block is kept
+        // for the next model, whose upload is ordered behind them on the same
+        // stream; only tables that other streams have used need a full wait.
+        if (model->foreign)
+            (void)hipDeviceSynchronize();
+        if (model->ctx->blob_cache.size() < 4) {
+            model->ctx->blob_cache.push_back({model->d_blob, model->blob_bytes, model->use_stream});
+        } else {
+            (void)hipStreamSynchronize(model->use_stream);
             (void)hipFree(model->d_blob);
+        }
     }
     delete model;
     return HF_OK;
@@ -2469,6 +2534,8 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: null pointer");
     if (!model->has_encode)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: model was built for decoding only");
+    if (int rc0 = model_on_stream(ctx, model))
+        return rc0;
     if (lead_bits > 7)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: lead_bits must be 0..7");
     if ((uintptr_t)d_out & 3)
@@ -2625,6 +2692,8 @@ static int fill_dec_params(hf_ctx *ctx, const hf_model *model, const uint8_t *d_
         return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: null pointer");
     if ((uintptr_t)d_in & 3)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: d_in must be 4-byte aligned");
+    if (int rc0 = model_on_stream(ctx, model))
+        return rc0;
     p->in = d_in;
     p->in_bytes = in_bytes;
     p->bit_base = bit_base;

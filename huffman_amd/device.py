@@ -111,6 +111,7 @@ class DeviceModel:
 
     def __init__(self, codes=None, lens=None, *, table=None, device=None):
         self.ctx = Context.get(device)
+        self.ctx.bind_stream()  # the tables are uploaded on the current stream
         h = C.c_void_p()
         if table is None:
             self.codes = _np_u64(codes)
