@@ -597,3 +597,29 @@ def test_unaligned_buffers(dev, orc, in_off, out_off):
     cb, so = dev.build_gap_array(comp[out_off:], nbytes, model, n)
     nc, ns = dev.gap_layout(n, 64)
     assert torch.equal(cb[:nc], bufs.chunk_bits[:nc]) and torch.equal(so[:ns], bufs.seg_off[:ns])
+
+
+def test_models_created_and_used_on_different_streams(dev, orc):
+    """Tables are uploaded asynchronously on the stream current at creation; a
+    kernel on another stream has to wait for that upload, and a destroyed
+    model's device block is reused by the next model without stalling."""
+    import torch
+
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rnd in range(12):
+        kind = ["zipf", "testfile", "geometric", "uniform"][rnd % 4]
+        data = synth.generate_host(kind, 200003 + 977 * rnd, seed=100 + rnd)
+        codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+        want, _ = orc.encode_slice(data, codes, lens)
+        make, use = (s1, s2) if rnd % 2 == 0 else (s2, s1)
+        with torch.cuda.stream(make):
+            gpu_data = to_gpu(data)
+            model = dev.DeviceModel(codes, lens)  # replaces (and destroys) the previous one
+        use.wait_stream(make)  # for the input tensor; the tables are the library's business
+        with torch.cuda.stream(use if rnd % 3 else make):
+            enc = dev.encode(gpu_data, model)
+            out = dev.decode(enc, model)
+            got = enc.stream().cpu().numpy()
+            back = out.cpu().numpy()
+        assert np.array_equal(got, want)
+        assert np.array_equal(back, data)
