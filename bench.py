@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--chunk-syms", type=int, default=hd.DEFAULT_CHUNK_SYMS)
     ap.add_argument("--enc-mode", type=int, default=1)
     ap.add_argument("--gather", action="store_true", help="also gather the shards to rank 0")
+    ap.add_argument("--no-plan", action="store_true",
+                    help="encode without the batch histograms of the counting pass "
+                         "(single-pass chained scan instead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--seed", type=int, default=2024)
@@ -100,6 +103,9 @@ def main():
     cs = args.chunk_syms
 
     d_hist = torch.empty(256, dtype=torch.int64, device=dev)
+    # the counting pass also records a histogram per 64 Ki symbols: with the
+    # code lengths they place every batch of the stream before the encoder runs
+    batch_hist = None if args.no_plan else hd.new_batch_hist(n, dev)
     out = torch.empty(n, dtype=torch.uint8, device=dev)
     dres = torch.zeros(4, dtype=torch.int64, device=dev)
     st_hist, st_enc, st_dec = Stage(), Stage(), Stage()
@@ -111,7 +117,7 @@ def main():
         # pass 1: histogram
         if timed:
             st_hist.start()
-        hd.histogram_async(data, d_hist)
+        hd.histogram_async(data, d_hist, batch_hist=batch_hist)
         if timed:
             st_hist.stop()
         # host: codebook, then device tables.  With several ranks one all-gather
@@ -136,7 +142,7 @@ def main():
         # pass 2: encode
         if timed:
             st_enc.start()
-        hd.encode_async(data, model, bufs, lead_bits=lead)
+        hd.encode_async(data, model, bufs, lead_bits=lead, plan=batch_hist)
         if timed:
             st_enc.stop()
         # the stream length is needed on the host (and is known from the histogram)
@@ -222,7 +228,7 @@ def main():
                          "codebook + encode + gap-array decode"),
             "bytes_per_gpu": n,
             "chunk_syms": cs,
-            "enc_mode": args.enc_mode,
+            "enc_mode": "planned" if batch_hist is not None else args.enc_mode,
             "compressed_ratio": round(C / n, 4),
             "max_code_len": int(state["lens"].max()),
             "gather_to_root": bool(args.gather),

@@ -27,6 +27,7 @@ HF_ERR_INTERNAL = 8
 HF_ERR_UNSUPPORTED = 9
 HF_RES_WORDS = 4
 HF_SEG_CHUNKS = 256
+HF_PLAN_BATCH = 65536
 
 # every symbol include/hfgpu.h declares, with its signature
 SIGNATURES = {
@@ -40,6 +41,9 @@ SIGNATURES = {
     "hf_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "hf_histogram_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "hf_histogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
+    "hf_batch_hist_bytes": (C.c_uint64, [C.c_uint64]),
+    "hf_histogram_batches_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                             C.c_void_p]),
     "hf_codeword_lengths_inplace": (C.c_int, [u64p, C.c_uint64]),
     "hf_sort_by_value": (C.c_int, [u64p, C.c_uint64, u64p, u64p, u64p]),
     "hf_codewords_from_lengths": (C.c_int, [u64p, C.c_uint64, u64p, u64p]),
@@ -56,6 +60,9 @@ SIGNATURES = {
     "hf_encode_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                   C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "hf_encode_planned_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hf_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                             C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, u64p]),
     "hf_encoder_write_value": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p, u64p,

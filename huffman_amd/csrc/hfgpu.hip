@@ -158,6 +158,93 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const uint8_t *__res
     }
 }
 
+// The same histogram, and in addition one histogram per batch of
+// HF_PLAN_BATCH consecutive symbols (uint32_t[256] each).  Whatever codebook
+// the global histogram leads to, a batch's histogram times the code lengths is
+// that batch's bit total, so the encoder can place every batch without
+// reading the input a second time and without any exchange between its
+// workgroups.  A workgroup counts a batch (512 lanes x 8 x 16 bytes) while
+// the loads of its next batch are in flight, then sums and clears the 32
+// columns of every bin.
+constexpr uint32_t PLAN_BATCH = HF_PLAN_BATCH;
+constexpr int PLAN_VECS = PLAN_BATCH / 16 / HIST_THREADS; // 16-byte vectors per lane and batch
+
+template <bool ALIGNED>
+__device__ __forceinline__ void hist_batch_load(const uint8_t *__restrict__ in, uint64_t n,
+                                                uint64_t b, uint4 (&x)[PLAN_VECS])
+{
+    const uint64_t base = b * PLAN_BATCH;
+    if (ALIGNED && base + PLAN_BATCH <= n) {
+        const uint4 *vin = reinterpret_cast<const uint4 *>(in + base);
+#pragma unroll
+        for (int k = 0; k < PLAN_VECS; ++k)
+            x[k] = vin[threadIdx.x + k * HIST_THREADS];
+    }
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(HIST_THREADS) void hist_batches_kernel(
+    const uint8_t *__restrict__ in, uint64_t n, unsigned long long *__restrict__ hist,
+    uint32_t *__restrict__ batch_hist, uint64_t n_batches)
+{
+    __shared__ __align__(16) uint32_t bins[256 * HIST_COLS];
+    for (uint32_t i = threadIdx.x; i < 256 * HIST_COLS; i += HIST_THREADS)
+        bins[i] = 0;
+    __syncthreads();
+    uint32_t *col = bins + (threadIdx.x & (HIST_COLS - 1));
+    // column sums: lanes 2b and 2b + 1 take 16 columns of bin b each, as four
+    // 16-byte pieces in an order that keeps 16 neighbouring lanes on 16
+    // different bank groups
+    const uint32_t bin = threadIdx.x >> 1, half = threadIdx.x & 1u;
+    uint4 *mine = reinterpret_cast<uint4 *>(bins + bin * HIST_COLS + half * 16);
+    unsigned long long running = 0;
+
+    uint4 x[PLAN_VECS], y[PLAN_VECS];
+    uint64_t b = blockIdx.x;
+    if (b < n_batches)
+        hist_batch_load<ALIGNED>(in, n, b, x);
+    for (; b < n_batches; b += gridDim.x) {
+        const uint64_t bn = b + gridDim.x;
+        if (bn < n_batches)
+            hist_batch_load<ALIGNED>(in, n, bn, y);
+        const uint64_t base = b * PLAN_BATCH;
+        if (ALIGNED && base + PLAN_BATCH <= n) {
+#pragma unroll
+            for (int k = 0; k < PLAN_VECS; ++k) {
+                hist_add4(col, x[k].x);
+                hist_add4(col, x[k].y);
+                hist_add4(col, x[k].z);
+                hist_add4(col, x[k].w);
+            }
+        } else { // ragged last batch, or an input that is not 16-byte aligned
+            const uint64_t end = base + PLAN_BATCH < n ? base + PLAN_BATCH : n;
+            for (uint64_t i = base + threadIdx.x; i < end; i += HIST_THREADS)
+                __hip_atomic_fetch_add(col + ((uint32_t)in[i] << 5), 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        uint32_t s = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t piece = (k + (threadIdx.x >> 3)) & 3u;
+            const uint4 v = mine[piece];
+            mine[piece] = make_uint4(0, 0, 0, 0);
+            s += v.x + v.y + v.z + v.w;
+        }
+        s += __shfl_xor(s, 1, 64);
+        if (half == 0) {
+            batch_hist[b * 256 + bin] = s;
+            running += s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PLAN_VECS; ++k)
+            x[k] = y[k];
+    }
+    if (half == 0 && running)
+        atomicAdd(&hist[bin], running);
+}
+
 // ------------------------------------------------------------------- encode
 //
 // A tile is 16384 consecutive symbols: 512 threads x a run of 32 consecutive
@@ -191,6 +278,7 @@ constexpr int ENC_WINW = 5120;                  // words of stream image per pas
 constexpr int ENC_REPL = 1;                     // replicas of the {code, len} table in LDS
 constexpr int ENC_BATCH = 4;                    // consecutive tiles per workgroup
 constexpr int ENC_MIN_WAVES = 6;                // waves per SIMD the register budget allows
+static_assert(ENC_TILE * ENC_BATCH == HF_PLAN_BATCH, "a planned batch is the encoder's batch");
 constexpr uint32_t ENC_LONG_FLAG = 1u << 24;    // len word of a code above 32 bits: flag | len (four cannot wrap)
 
 constexpr unsigned long long DESC_AGG = 1ull << 62;  // batch total published
@@ -214,6 +302,7 @@ struct EncParams {
     uint64_t n_chunks;
     uint64_t *result;
     uint64_t *tile_off;       // three-kernel mode: exclusive bit offsets per tile
+    const uint64_t *plan_off; // planned mode: exclusive bit offsets per batch, [n_batches] = total
     unsigned long long *desc; // chained mode: per-tile descriptors (zeroed)
     uint32_t *ticket;         // chained mode: tile counter (zeroed)
     uint32_t *abort_flag;     // chained mode: set when a wait expired
@@ -601,18 +690,42 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
     }
 }
 
-// Three-kernel mode, kernel 2: in-place exclusive scan of the tile totals by
-// one workgroup; the grand total lands in tile_off[n] and result[0].
-__global__ __launch_bounds__(256) void enc_scan_tiles_kernel(uint64_t *tile_off, uint32_t n,
-                                                             uint64_t *result)
+// Planned mode, kernel 1: bit total of every batch from its histogram and the
+// code lengths (one wave per batch, four bins per lane).
+__global__ __launch_bounds__(ENC_THREADS) void enc_plan_bits_kernel(
+    const uint32_t *__restrict__ batch_hist, const uint8_t *__restrict__ len8, uint64_t *off,
+    uint32_t n_batches)
 {
-    __shared__ uint64_t s_part[256];
-    __shared__ uint64_t s_carry;
-    if (threadIdx.x == 0)
-        s_carry = 0;
-    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = blockIdx.x * ENC_WAVES + (threadIdx.x >> 6);
+    if (b >= n_batches)
+        return;
+    const uint4 h = reinterpret_cast<const uint4 *>(batch_hist + (uint64_t)b * 256)[lane];
+    const uint32_t l4 = reinterpret_cast<const uint32_t *>(len8)[lane];
+    // up to 65536 symbols of up to 57 bits each: 64-bit sums
+    uint64_t sum = (uint64_t)h.x * (l4 & 0xffu) + (uint64_t)h.y * ((l4 >> 8) & 0xffu) +
+                   (uint64_t)h.z * ((l4 >> 16) & 0xffu) + (uint64_t)h.w * (l4 >> 24);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        sum += __shfl_xor(sum, d, 64);
+    if (lane == 0)
+        off[b] = sum;
+}
+
+// Three-kernel and planned mode, kernel 2: in-place exclusive scan of the
+// tile (batch) totals by one workgroup of 1024 lanes, 16 entries per lane and
+// round: wave scans by shuffles, one LDS hand-over between the 16 waves.  The
+// grand total lands in tile_off[n] and result[0].
+constexpr int SCAN_THREADS = 1024;
+__global__ __launch_bounds__(SCAN_THREADS) void enc_scan_tiles_kernel(uint64_t *tile_off,
+                                                                      uint32_t n,
+                                                                      uint64_t *result)
+{
+    __shared__ uint64_t s_wave[SCAN_THREADS / 64];
     constexpr uint32_t PER = 16;
-    for (uint32_t base = 0; base < n; base += 256 * PER) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint64_t carry = 0; // total of all earlier rounds (every lane keeps its own copy)
+    for (uint32_t base = 0; base < n; base += SCAN_THREADS * PER) {
         const uint32_t i0 = base + threadIdx.x * PER;
         uint64_t v[PER];
         uint64_t sum = 0;
@@ -621,29 +734,36 @@ __global__ __launch_bounds__(256) void enc_scan_tiles_kernel(uint64_t *tile_off,
             v[k] = (i0 + k < n) ? tile_off[i0 + k] : 0;
             sum += v[k];
         }
-        s_part[threadIdx.x] = sum;
-        __syncthreads();
-        for (uint32_t d = 1; d < 256; d <<= 1) { // Hillis-Steele over 256 partial sums
-            uint64_t t = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
-            __syncthreads();
-            s_part[threadIdx.x] += t;
-            __syncthreads();
+        uint64_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d)
+                incl += t;
         }
-        uint64_t run = s_carry + s_part[threadIdx.x] - sum;
+        if (lane == 63)
+            s_wave[wv] = incl;
+        __syncthreads();
+        uint64_t before = 0, round_total = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < SCAN_THREADS / 64; ++i) {
+            const uint64_t x = s_wave[i];
+            before += i < wv ? x : 0;
+            round_total += x;
+        }
+        uint64_t run = carry + before + incl - sum;
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             if (i0 + k < n)
                 tile_off[i0 + k] = run;
             run += v[k];
         }
-        __syncthreads();
-        if (threadIdx.x == 255)
-            s_carry += s_part[255];
-        __syncthreads();
+        carry += round_total;
+        __syncthreads(); // s_wave is rewritten in the next round
     }
     if (threadIdx.x == 0) {
-        tile_off[n] = s_carry;
-        result[HF_RES_TOTAL_BITS] = s_carry;
+        tile_off[n] = carry;
+        result[HF_RES_TOTAL_BITS] = carry;
     }
 }
 
@@ -952,15 +1072,27 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
         }
     } else {
         if (threadIdx.x == 0) {
-            s_start = p.tile_off[tile0] + p.lead_bits;
-            s_ctl[0] = 1u;
+            if (p.plan_off) {
+                // the batch's place was worked out from its histogram: if the
+                // totals disagree, the histograms belong to other data
+                const uint64_t at = p.plan_off[batch];
+                const bool ok = p.plan_off[batch + 1] - at == (uint64_t)batch_bits;
+                if (!ok)
+                    atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
+                             (unsigned long long)HF_FLAG_PLAN);
+                s_start = at + p.lead_bits;
+                s_ctl[0] = ok ? 1u : 0u;
+            } else {
+                s_start = p.tile_off[tile0] + p.lead_bits;
+                s_ctl[0] = 1u;
+            }
         }
     }
     ENC_TRACE(5);
     __syncthreads();
     ENC_TRACE(6);
     if (!s_ctl[0])
-        return; // a wait expired: the host reports HF_ERR_INTERNAL
+        return; // a wait expired, or the plan is not this input's: the host reports it
     uint64_t S = s_start;
     if (p.debug & 1u)
         return;
@@ -2127,6 +2259,8 @@ int flags_to_status(hf_ctx *ctx, uint64_t flags)
 {
     if (flags & HF_FLAG_TIMEOUT)
         return fail(ctx, HF_ERR_INTERNAL, "a device-side inter-workgroup wait expired");
+    if (flags & HF_FLAG_PLAN)
+        return fail(ctx, HF_ERR_BAD_ARG, "the batch histograms do not belong to this input");
     if (flags & HF_FLAG_CAPACITY)
         return fail(ctx, HF_ERR_CAPACITY, "output buffer too small");
     if (flags & HF_FLAG_DECODE)
@@ -2370,6 +2504,33 @@ int hf_histogram_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d
     return HF_OK;
 }
 
+uint64_t hf_batch_hist_bytes(uint64_t n)
+{
+    return (n + PLAN_BATCH - 1) / PLAN_BATCH * 256 * sizeof(uint32_t);
+}
+
+int hf_histogram_batches_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d_hist,
+                               uint32_t *d_batch_hist)
+{
+    if (!ctx || !d_hist || (!d_in && n) || (!d_batch_hist && n))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram_batches: null pointer");
+    if (n >= (1ull << 40))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram_batches: n must be below 2^40");
+    if ((uintptr_t)d_batch_hist & 15)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram_batches: d_batch_hist must be 16-byte aligned");
+    HF_HIP(ctx, hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), ctx->stream));
+    if (n == 0)
+        return HF_OK;
+    const uint64_t n_batches = (n + PLAN_BATCH - 1) / PLAN_BATCH;
+    uint64_t cap = ctx->hist_grid > 0 ? (uint64_t)ctx->hist_grid : (uint64_t)ctx->num_cus * 2;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(n_batches, cap));
+    auto kern = ((uintptr_t)d_in & 15) == 0 ? hist_batches_kernel<true> : hist_batches_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, d_in, n,
+                       reinterpret_cast<unsigned long long *>(d_hist), d_batch_hist, n_batches);
+    HF_HIP(ctx, hipGetLastError());
+    return HF_OK;
+}
+
 int hf_histogram(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t hist[256])
 {
     if (!ctx || !hist)
@@ -2526,9 +2687,15 @@ int hf_gap_layout(uint64_t n, uint32_t chunk_syms, uint64_t *n_chunks, uint64_t 
     return HF_OK;
 }
 
-int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
-                    uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,
-                    uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint64_t *d_result)
+} // extern "C"
+
+namespace {
+
+// hf_encode_async and hf_encode_planned_async (d_batch_hist != null)
+int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
+                  uint32_t lead_bits, const uint32_t *d_batch_hist, uint8_t *d_out,
+                  uint64_t out_cap, uint32_t chunk_syms, uint16_t *d_chunk_bits,
+                  uint64_t *d_seg_off, uint64_t *d_result)
 {
     if (!ctx || !model || !d_result || (!d_in && n) || (!d_out && out_cap))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: null pointer");
@@ -2595,12 +2762,21 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     // batches whose tiles are all complete run the lean instantiation; the
     // ragged last batch (and everything, if the input is unaligned) the general one
     const uint32_t n_lean = p.aligned16 ? (uint32_t)(n / ((uint64_t)ENC_TILE * ENC_BATCH)) : 0u;
-    const bool chained = ctx->enc_mode != 0;
-    if (!chained) {
+    const bool planned = d_batch_hist != nullptr;
+    const bool chained = !planned && ctx->enc_mode != 0;
+    if (planned) {
+        uint64_t *off = static_cast<uint64_t *>(ctx->scratch);
+        hipLaunchKernelGGL(enc_plan_bits_kernel, dim3((n_batches + ENC_WAVES - 1) / ENC_WAVES),
+                           dim3(ENC_THREADS), 0, ctx->stream, d_batch_hist, model->d_len8, off,
+                           n_batches);
+        hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, off,
+                           n_batches, d_result);
+        p.plan_off = off;
+    } else if (!chained) {
         p.tile_off = static_cast<uint64_t *>(ctx->scratch);
         hipLaunchKernelGGL(enc_tile_bits_kernel, dim3(n_tiles), dim3(ENC_THREADS), 0, ctx->stream,
                            p);
-        hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(256), 0, ctx->stream, p.tile_off,
+        hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, p.tile_off,
                            n_tiles, d_result);
     } else {
         HF_HIP(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
@@ -2630,6 +2806,31 @@ int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     }
     HF_HIP(ctx, hipGetLastError());
     return HF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
+                    uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,
+                    uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint64_t *d_result)
+{
+    return encode_launch(ctx, model, d_in, n, lead_bits, nullptr, d_out, out_cap, chunk_syms,
+                         d_chunk_bits, d_seg_off, d_result);
+}
+
+int hf_encode_planned_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
+                            uint32_t lead_bits, const uint32_t *d_batch_hist, uint8_t *d_out,
+                            uint64_t out_cap, uint32_t chunk_syms, uint16_t *d_chunk_bits,
+                            uint64_t *d_seg_off, uint64_t *d_result)
+{
+    if (!d_batch_hist && n)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_planned: null batch histograms");
+    if ((uintptr_t)d_batch_hist & 15)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_planned: d_batch_hist must be 16-byte aligned");
+    return encode_launch(ctx, model, d_in, n, lead_bits, d_batch_hist, d_out, out_cap, chunk_syms,
+                         d_chunk_bits, d_seg_off, d_result);
 }
 
 int hf_encode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,

@@ -74,15 +74,34 @@ def _check_u8(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def histogram_async(t: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """256-bin byte histogram, left in device memory (int64[256])."""
+def histogram_async(t: torch.Tensor, out: torch.Tensor | None = None,
+                    batch_hist: torch.Tensor | None = None) -> torch.Tensor:
+    """256-bin byte histogram, left in device memory (int64[256]).  With
+    batch_hist (see new_batch_hist) the pass also records one histogram per
+    65536 symbols, which encode_async(..., plan=batch_hist) turns into the
+    place of every batch in the stream."""
     t = _check_u8(t)
     ctx = Context.get(t.device)
     ctx.bind_stream()
     if out is None:
         out = torch.empty(256, dtype=torch.int64, device=t.device)
-    ctx.check(lib().hf_histogram_async(ctx.handle, t.data_ptr(), t.numel(), out.data_ptr()))
+    if batch_hist is None:
+        ctx.check(lib().hf_histogram_async(ctx.handle, t.data_ptr(), t.numel(), out.data_ptr()))
+    else:
+        if batch_hist.numel() * batch_hist.element_size() < batch_hist_bytes(t.numel()):
+            raise ValueError("batch_hist is too small for this input")
+        ctx.check(lib().hf_histogram_batches_async(ctx.handle, t.data_ptr(), t.numel(),
+                                                   out.data_ptr(), batch_hist.data_ptr()))
     return out
+
+
+def batch_hist_bytes(n: int) -> int:
+    return int(lib().hf_batch_hist_bytes(n))
+
+
+def new_batch_hist(n: int, device) -> torch.Tensor:
+    """Device buffer for the per-batch histograms of an n-symbol input."""
+    return torch.empty(max(batch_hist_bytes(n) // 4, 4), dtype=torch.int32, device=device)
 
 
 def histogram(t: torch.Tensor) -> np.ndarray:
@@ -194,15 +213,22 @@ class EncodeBuffers:
 
 
 def encode_async(t: torch.Tensor, model: DeviceModel, bufs: EncodeBuffers,
-                 lead_bits: int = 0) -> None:
-    """Enqueue one encode; results land in bufs (bufs.result holds bits/flags)."""
+                 lead_bits: int = 0, plan: torch.Tensor | None = None) -> None:
+    """Enqueue one encode; results land in bufs (bufs.result holds bits/flags).
+    plan = the batch histograms histogram_async recorded for this same input."""
     ctx = model.ctx
     ctx.bind_stream()
     cb = bufs.chunk_bits.data_ptr() if bufs.chunk_bits is not None else None
     so = bufs.seg_off.data_ptr() if bufs.seg_off is not None else None
-    ctx.check(lib().hf_encode_async(ctx.handle, model.handle, t.data_ptr(), t.numel(), lead_bits,
-                                    bufs.data.data_ptr(), bufs.cap, bufs.chunk_syms, cb, so,
-                                    bufs.result.data_ptr()))
+    if plan is None:
+        ctx.check(lib().hf_encode_async(ctx.handle, model.handle, t.data_ptr(), t.numel(),
+                                        lead_bits, bufs.data.data_ptr(), bufs.cap,
+                                        bufs.chunk_syms, cb, so, bufs.result.data_ptr()))
+    else:
+        ctx.check(lib().hf_encode_planned_async(ctx.handle, model.handle, t.data_ptr(), t.numel(),
+                                                lead_bits, plan.data_ptr(), bufs.data.data_ptr(),
+                                                bufs.cap, bufs.chunk_syms, cb, so,
+                                                bufs.result.data_ptr()))
 
 
 def encode(t: torch.Tensor, model: DeviceModel, chunk_syms: int = DEFAULT_CHUNK_SYMS,

@@ -57,11 +57,14 @@ enum { HF_RES_TOTAL_BITS = 0, HF_RES_FLAGS = 1, HF_RES_WORDS = 4 };
 enum {
     HF_FLAG_CAPACITY = 1u,  /* an output store was suppressed: buffer too small */
     HF_FLAG_DECODE = 2u,    /* window below the smallest key */
-    HF_FLAG_TIMEOUT = 4u    /* a bounded inter-workgroup wait expired */
+    HF_FLAG_TIMEOUT = 4u,   /* a bounded inter-workgroup wait expired */
+    HF_FLAG_PLAN = 8u       /* batch histograms do not belong to this input */
 };
 
 /* Granularity constants of the side metadata (the "gap array"). */
 enum { HF_SEG_CHUNKS = 256 }; /* chunks per segment */
+/* Symbols per batch of the per-batch histograms (hf_histogram_batches_async). */
+enum { HF_PLAN_BATCH = 65536 };
 
 /* ------------------------------------------------------------------ context */
 
@@ -91,6 +94,15 @@ HF_API int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value);
 HF_API int hf_histogram_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d_hist);
 /* Same, then copies the counts to host memory. */
 HF_API int hf_histogram(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t hist[256]);
+/* The same counting pass (src/huffman/mod.rs:59-65) that keeps what it learns
+ * about where the symbols are: besides d_hist it fills d_batch_hist with one
+ * histogram per HF_PLAN_BATCH consecutive symbols, ceil(n / HF_PLAN_BATCH) x
+ * 256 x uint32_t (hf_batch_hist_bytes(n) bytes, 1.6 % of n).  Given to
+ * hf_encode_planned_async together with the same input, they place every
+ * batch of the stream in advance, whatever codebook the histogram leads to. */
+HF_API uint64_t hf_batch_hist_bytes(uint64_t n);
+HF_API int hf_histogram_batches_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n,
+                                      uint64_t *d_hist, uint32_t *d_batch_hist);
 
 /* ------------------------------------- L1: src/huffman/mod.rs (host side) */
 
@@ -158,6 +170,20 @@ HF_API int hf_encode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_
                            uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap,
                            uint32_t chunk_syms, uint16_t *d_chunk_bits, uint64_t *d_seg_off,
                            uint64_t *d_result);
+/* hf_encode_async (src/huffman/encode.rs:91-136) for an input whose batch
+ * histograms are at hand (hf_histogram_batches_async over the same d_in, n):
+ * same stream, same gap array, but the start bit of every batch comes from
+ * the histograms and the code lengths, so the workgroups neither take tickets
+ * nor wait for each other.  Histograms that do not belong to the input are
+ * detected (a batch's planned and actual bit totals differ): the stream is
+ * then invalid and the flags carry HF_FLAG_PLAN (HF_ERR_BAD_ARG from the
+ * synchronous callers). */
+HF_API int hf_encode_planned_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in,
+                                   uint64_t n, uint32_t lead_bits,
+                                   const uint32_t *d_batch_hist, uint8_t *d_out,
+                                   uint64_t out_cap, uint32_t chunk_syms,
+                                   uint16_t *d_chunk_bits, uint64_t *d_seg_off,
+                                   uint64_t *d_result);
 /* Synchronous form; *total_bits receives the bit count (lead_bits excluded). */
 HF_API int hf_encode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
                      uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,

@@ -623,3 +623,69 @@ def test_models_created_and_used_on_different_streams(dev, orc):
             back = out.cpu().numpy()
         assert np.array_equal(got, want)
         assert np.array_equal(back, data)
+
+
+# ---- counting pass that records a histogram per 65536 symbols, and the
+# ---- encoder that takes every batch's place in the stream from them
+
+@pytest.mark.parametrize("n,off", [(1, 0), (65535, 0), (65536, 0), (65537, 3), (300001, 0),
+                                   (5 * 65536, 16), ((1 << 22) + 77, 1)])
+def test_batch_histograms_match_numpy(dev, orc, n, off):
+    import torch
+
+    host = synth.generate_host("zipf", n + off, seed=n)
+    data = to_gpu(host)[off:]
+    bh = dev.new_batch_hist(n, data.device)
+    d_hist = dev.histogram_async(data, batch_hist=bh)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_hist.cpu().numpy().astype(np.uint64), orc.histogram(host[off:]))
+    nb = (n + 65535) // 65536
+    got = bh[: nb * 256].cpu().numpy().reshape(nb, 256)
+    want = np.stack([np.bincount(host[off + b * 65536: off + min(n, (b + 1) * 65536)], minlength=256)
+                     for b in range(nb)])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind", ["zipf", "testfile", "uniform", "geometric"])
+@pytest.mark.parametrize("n,off,lead,cs", [(1, 0, 0, 64), (65536, 0, 0, 64), (65537, 0, 3, 128),
+                                           (200003, 5, 7, 64), ((1 << 21) + 9, 0, 0, 256),
+                                           (3 * 65536, 16, 1, 64)])
+def test_planned_encode_matches_oracle(dev, orc, kind, n, off, lead, cs):
+    import torch
+
+    host = synth.generate_host(kind, n + off, seed=n + lead)
+    data = to_gpu(host)[off:]
+    codes, lens = orc.generate_extended_codewords(orc.histogram(host[off:]))
+    want, _ = orc.encode_slice(host[off:], codes, lens)
+    model = dev.DeviceModel(codes, lens)
+    bh = dev.new_batch_hist(n, data.device)
+    dev.histogram_async(data, batch_hist=bh)
+    planned = dev.EncodeBuffers(model, n, cs, lead_bits=lead)
+    chained = dev.EncodeBuffers(model, n, cs, lead_bits=lead)
+    dev.encode_async(data, model, planned, lead_bits=lead, plan=bh)
+    dev.encode_async(data, model, chained, lead_bits=lead)
+    torch.cuda.synchronize()
+    total = int(np.asarray(lens, dtype=np.uint64)[host[off:]].sum())
+    assert planned.result.tolist() == [total, 0, 0, 0]
+    nbytes = (lead + total + 7) // 8
+    assert torch.equal(planned.data[:nbytes], chained.data[:nbytes])
+    assert torch.equal(planned.chunk_bits, chained.chunk_bits)
+    assert torch.equal(planned.seg_off, chained.seg_off)
+    if lead == 0:
+        assert np.array_equal(planned.data[:nbytes].cpu().numpy(), want)
+
+
+def test_planned_encode_detects_histograms_of_other_data(dev, orc):
+    import torch
+
+    n = 400000
+    a = synth.generate_host("zipf", n, seed=1)
+    b = synth.generate_host("zipf", n, seed=2)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(a))
+    model = dev.DeviceModel(codes, lens)
+    bh = dev.new_batch_hist(n, "cuda")
+    dev.histogram_async(to_gpu(b), batch_hist=bh)  # counted on b ...
+    bufs = dev.EncodeBuffers(model, n, 64)
+    dev.encode_async(to_gpu(a), model, bufs, plan=bh)  # ... used for a
+    torch.cuda.synchronize()
+    assert int(bufs.result[1].item()) & 8  # HF_FLAG_PLAN
