@@ -46,6 +46,10 @@ def timed(fn):
 timed(lambda: hd.encode_async(data, model, bufs))  # clocks settle during the first passes
 h = timed(lambda: hd.histogram_async(data, d_hist))
 e = timed(lambda: hd.encode_async(data, model, bufs))
+plan = hd.new_batch_hist(n, data.device)
+hb = timed(lambda: hd.histogram_async(data, d_hist, batch_hist=plan))
+ep = timed(lambda: hd.encode_async(data, model, bufs, plan=plan))
 d = timed(lambda: hd.decode_async(bufs.data, nbytes, model, n, 64, bufs.chunk_bits, bufs.seg_off, out, dres))
 assert torch.equal(out, data)
-print(f"{kind} {mib} MiB  median/min ms: hist {h[0]:.4f}/{h[1]:.4f}  enc {e[0]:.4f}/{e[1]:.4f}  dec {d[0]:.4f}/{d[1]:.4f}")
+print(f"{kind} {mib} MiB  median/min ms: hist {h[0]:.4f}/{h[1]:.4f}  enc {e[0]:.4f}/{e[1]:.4f}  dec {d[0]:.4f}/{d[1]:.4f}"
+      f"  | hist+batches {hb[0]:.4f}/{hb[1]:.4f}  enc planned {ep[0]:.4f}/{ep[1]:.4f}")

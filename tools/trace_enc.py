@@ -1,7 +1,7 @@
 """Phase timeline of the encode kernel.  Needs a library built with
 HF_ENC_TRACE=1 python huffman_amd/build.py: under the context option debug=16
 its kernel stamps the wall clock at every phase boundary into the tail of the
-output buffer.  python tools/trace_enc.py [kind]"""
+output buffer.  python tools/trace_enc.py [kind] [planned]"""
 import sys
 import numpy as np
 import torch
@@ -16,9 +16,13 @@ codes, lens = hd.build_codebook(hist)
 model = hd.DeviceModel(codes, lens)
 bufs = hd.EncodeBuffers(model, n, 64)
 ctx = model.ctx
+plan = None
+if len(sys.argv) > 2 and sys.argv[2] == "planned":
+    plan = hd.new_batch_hist(n, data.device)
+    hd.histogram_async(data, batch_hist=plan)
 ctx.set_option("debug", 16)
 for _ in range(3):
-    hd.encode_async(data, model, bufs)
+    hd.encode_async(data, model, bufs, plan=plan)
 torch.cuda.synchronize()
 ctx.set_option("debug", 0)
 n_batches = n // 65536
@@ -44,20 +48,22 @@ for who, x in (("thread 0 (wave 0)", a), ("thread 448 (wave 7)", b)):
         d = (x[sel, idx[k + 1]] - x[sel, idx[k]]) / 100.0
         print("  %-16s mean %6.2f  median %6.2f  p90 %6.2f us" % (lab[k], d.mean(), np.median(d), np.percentile(d, 90)))
 pl = a[sel, 19] & 0xffffffff; st = a[sel, 19] >> 32
-print("lookback polls mean %.2f p90 %d; steps mean %.2f p90 %d" % (pl.mean(), np.percentile(pl, 90), st.mean(), np.percentile(st, 90)))
+if plan is None:
+    print("lookback polls mean %.2f p90 %d; steps mean %.2f p90 %d" % (pl.mean(), np.percentile(pl, 90), st.mean(), np.percentile(st, 90)))
 # concurrency: batches alive at mid time
 mid = (a[:, 0].min() + a[:, 18].max()) // 2
 alive = ((a[:, 0] <= mid) & (a[:, 18] >= mid)).sum()
 print("WGs alive at mid-kernel:", int(alive))
-# how late are the predecessors' totals compared with this batch's own?
-t4 = a[:, 4].astype(np.float64) / 100.0
-t5 = a[:, 5].astype(np.float64) / 100.0
-for win in (8, 32, 64, 128):
-    idxs = np.arange(2000, n_batches - 1000)
-    m = np.max(np.stack([t4[idxs - k] for k in range(1, win + 1)]), axis=0)
-    lag = m - t4[idxs]
-    tail = t5[idxs] - np.maximum(m, t4[idxs])
-    print("window %3d: slowest predecessor total vs own: mean %+.2f us (p10 %+.2f, p90 %+.2f); look-back end after both: mean %.2f us"
-          % (win, lag.mean(), np.percentile(lag, 10), np.percentile(lag, 90), tail.mean()))
-start = a[:, 0].astype(np.float64) / 100.0
-print("start spacing to predecessor: mean %.3f us, p10 %.3f p90 %.3f" % ((start[idxs] - start[idxs - 1]).mean(), np.percentile(start[idxs] - start[idxs - 1], 10), np.percentile(start[idxs] - start[idxs - 1], 90)))
+if plan is None:
+    # how late are the predecessors' totals compared with this batch's own?
+    t4 = a[:, 4].astype(np.float64) / 100.0
+    t5 = a[:, 5].astype(np.float64) / 100.0
+    for win in (8, 32, 64, 128):
+        idxs = np.arange(2000, n_batches - 1000)
+        m = np.max(np.stack([t4[idxs - k] for k in range(1, win + 1)]), axis=0)
+        lag = m - t4[idxs]
+        tail = t5[idxs] - np.maximum(m, t4[idxs])
+        print("window %3d: slowest predecessor total vs own: mean %+.2f us (p10 %+.2f, p90 %+.2f); look-back end after both: mean %.2f us"
+              % (win, lag.mean(), np.percentile(lag, 10), np.percentile(lag, 90), tail.mean()))
+    start = a[:, 0].astype(np.float64) / 100.0
+    print("start spacing to predecessor: mean %.3f us, p10 %.3f p90 %.3f" % ((start[idxs] - start[idxs - 1]).mean(), np.percentile(start[idxs] - start[idxs - 1], 10), np.percentile(start[idxs] - start[idxs - 1], 90)))
