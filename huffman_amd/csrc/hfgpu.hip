@@ -302,7 +302,11 @@ struct EncParams {
     uint64_t n_chunks;
     uint64_t *result;
     uint64_t *tile_off;       // three-kernel mode: exclusive bit offsets per tile
-    const uint64_t *plan_off; // planned mode: exclusive bit offsets per batch, [n_batches] = total
+    // planned mode: start bit of every group of ENC_WAVES batches (scanned, [n_groups] = total),
+    // start of every batch inside its group, and every batch's bit total
+    const uint64_t *plan_off;
+    const uint32_t *plan_local;
+    const uint32_t *plan_tot;
     unsigned long long *desc; // chained mode: per-tile descriptors (zeroed)
     uint32_t *ticket;         // chained mode: tile counter (zeroed)
     uint32_t *abort_flag;     // chained mode: set when a wait expired
@@ -691,25 +695,43 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
 }
 
 // Planned mode, kernel 1: bit total of every batch from its histogram and the
-// code lengths (one wave per batch, four bins per lane).
+// code lengths (one wave per batch, four bins per lane), the batch's start
+// inside its group of ENC_WAVES batches (= one workgroup here) and the group's
+// total, which kernel 2 scans: 8 times fewer entries for its single workgroup.
 __global__ __launch_bounds__(ENC_THREADS) void enc_plan_bits_kernel(
-    const uint32_t *__restrict__ batch_hist, const uint8_t *__restrict__ len8, uint64_t *off,
-    uint32_t n_batches)
+    const uint32_t *__restrict__ batch_hist, const uint8_t *__restrict__ len8,
+    uint64_t *group_off, uint32_t *local, uint32_t *tot, uint32_t n_batches)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t b = blockIdx.x * ENC_WAVES + (threadIdx.x >> 6);
-    if (b >= n_batches)
-        return;
-    const uint4 h = reinterpret_cast<const uint4 *>(batch_hist + (uint64_t)b * 256)[lane];
-    const uint32_t l4 = reinterpret_cast<const uint32_t *>(len8)[lane];
-    // up to 65536 symbols of up to 57 bits each: 64-bit sums
-    uint64_t sum = (uint64_t)h.x * (l4 & 0xffu) + (uint64_t)h.y * ((l4 >> 8) & 0xffu) +
-                   (uint64_t)h.z * ((l4 >> 16) & 0xffu) + (uint64_t)h.w * (l4 >> 24);
+    __shared__ uint32_t s_tot[ENC_WAVES];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * ENC_WAVES + wv;
+    uint32_t sum = 0; // at most 65536 symbols of at most 57 bits
+    if (b < n_batches) {
+        const uint4 h = reinterpret_cast<const uint4 *>(batch_hist + (uint64_t)b * 256)[lane];
+        const uint32_t l4 = reinterpret_cast<const uint32_t *>(len8)[lane];
+        sum = h.x * (l4 & 0xffu) + h.y * ((l4 >> 8) & 0xffu) + h.z * ((l4 >> 16) & 0xffu) +
+              h.w * (l4 >> 24);
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1)
         sum += __shfl_xor(sum, d, 64);
     if (lane == 0)
-        off[b] = sum;
+        s_tot[wv] = sum;
+    __syncthreads();
+    if (threadIdx.x < ENC_WAVES) {
+        uint32_t before = 0, all = 0;
+        for (uint32_t i = 0; i < ENC_WAVES; ++i) {
+            before += i < threadIdx.x ? s_tot[i] : 0u;
+            all += s_tot[i];
+        }
+        const uint32_t mine = blockIdx.x * ENC_WAVES + threadIdx.x;
+        if (mine < n_batches) {
+            local[mine] = before;
+            tot[mine] = s_tot[threadIdx.x];
+        }
+        if (threadIdx.x == 0)
+            group_off[blockIdx.x] = all;
+    }
 }
 
 // Three-kernel and planned mode, kernel 2: in-place exclusive scan of the
@@ -730,8 +752,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void enc_scan_tiles_kernel(uint64_t *
         uint64_t v[PER];
         uint64_t sum = 0;
 #pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) // unconditional loads: all 16 in flight together
+            v[k] = tile_off[min(i0 + k, n - 1)];
+#pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
-            v[k] = (i0 + k < n) ? tile_off[i0 + k] : 0;
+            v[k] = (i0 + k < n) ? v[k] : 0;
             sum += v[k];
         }
         uint64_t incl = sum;
@@ -1075,8 +1100,8 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
             if (p.plan_off) {
                 // the batch's place was worked out from its histogram: if the
                 // totals disagree, the histograms belong to other data
-                const uint64_t at = p.plan_off[batch];
-                const bool ok = p.plan_off[batch + 1] - at == (uint64_t)batch_bits;
+                const uint64_t at = p.plan_off[batch / ENC_WAVES] + p.plan_local[batch];
+                const bool ok = p.plan_tot[batch] == batch_bits;
                 if (!ok)
                     atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
                              (unsigned long long)HF_FLAG_PLAN);
@@ -2765,13 +2790,18 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
     const bool planned = d_batch_hist != nullptr;
     const bool chained = !planned && ctx->enc_mode != 0;
     if (planned) {
+        // scratch: group offsets (+ total) | start inside the group | bit total, per batch
+        const uint32_t n_groups = (n_batches + ENC_WAVES - 1) / ENC_WAVES;
         uint64_t *off = static_cast<uint64_t *>(ctx->scratch);
-        hipLaunchKernelGGL(enc_plan_bits_kernel, dim3((n_batches + ENC_WAVES - 1) / ENC_WAVES),
-                           dim3(ENC_THREADS), 0, ctx->stream, d_batch_hist, model->d_len8, off,
-                           n_batches);
+        uint32_t *local = reinterpret_cast<uint32_t *>(off + n_groups + 1);
+        uint32_t *tot = local + n_batches;
+        hipLaunchKernelGGL(enc_plan_bits_kernel, dim3(n_groups), dim3(ENC_THREADS), 0, ctx->stream,
+                           d_batch_hist, model->d_len8, off, local, tot, n_batches);
         hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, off,
-                           n_batches, d_result);
+                           n_groups, d_result);
         p.plan_off = off;
+        p.plan_local = local;
+        p.plan_tot = tot;
     } else if (!chained) {
         p.tile_off = static_cast<uint64_t *>(ctx->scratch);
         hipLaunchKernelGGL(enc_tile_bits_kernel, dim3(n_tiles), dim3(ENC_THREADS), 0, ctx->stream,
