@@ -2199,6 +2199,15 @@ struct hf_ctx {
     unsigned pinned_next = 0;
     void *arena = nullptr; // device staging of the *_host entry points (grow only)
     size_t arena_bytes = 0;
+    // option "kernel_timing": HIP events around the dominant kernel of every
+    // histogram / encode / decode call (on the stream it is launched on), kept
+    // in a ring until hf_ctx_kernel_ms collects them
+    struct Timed {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ring;
+        size_t pending = 0; // pairs recorded since the last collection
+    };
+    Timed timed[3];
+    bool kernel_timing = false;
 };
 
 struct hf_model {
@@ -2386,6 +2395,34 @@ bool valid_chunk_syms(uint32_t cs)
     return cs == 64 || cs == 128 || cs == 256;
 }
 
+// Kernel timing (option "kernel_timing"): the next free pair of the ring, or
+// nothing when the option is off or the ring is full.
+constexpr size_t TIMED_RING = 4096;
+std::pair<hipEvent_t, hipEvent_t> *timed_slot(hf_ctx *ctx, int kind)
+{
+    if (!ctx->kernel_timing)
+        return nullptr;
+    hf_ctx::Timed &t = ctx->timed[kind];
+    if (t.pending >= TIMED_RING)
+        return nullptr;
+    if (t.pending >= t.ring.size()) {
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)
+            return nullptr;
+        t.ring.push_back(ev);
+    }
+    return &t.ring[t.pending++];
+}
+#define HF_TIMED_LAUNCH(ctx, kind, launch)                                                    \
+    do {                                                                                      \
+        std::pair<hipEvent_t, hipEvent_t> *ev_ = timed_slot(ctx, kind);                       \
+        if (ev_)                                                                              \
+            (void)hipEventRecord(ev_->first, (ctx)->stream);                                  \
+        launch;                                                                               \
+        if (ev_)                                                                              \
+            (void)hipEventRecord(ev_->second, (ctx)->stream);                                 \
+    } while (0)
+
 // Work that reads a model's tables must come after their upload: on the
 // stream that carried the upload that is the case already, any other stream
 // waits for the upload's event (and the model remembers the foreign use).
@@ -2459,6 +2496,11 @@ int hf_ctx_destroy(hf_ctx *ctx)
         (void)hipFree(ctx->arena);
     for (auto &b : ctx->blob_cache)
         (void)hipFree(b.d);
+    for (auto &t : ctx->timed)
+        for (auto &ev : t.ring) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
     for (auto &ps : ctx->pinned) {
         if (ps.h)
             (void)hipHostFree(ps.h);
@@ -2487,6 +2529,24 @@ int hf_ctx_synchronize(hf_ctx *ctx)
     return HF_OK;
 }
 
+int hf_ctx_kernel_ms(hf_ctx *ctx, int kind, double *sum_ms, uint64_t *launches)
+{
+    if (!ctx || kind < 0 || kind > 2 || !sum_ms || !launches)
+        return HF_ERR_BAD_ARG;
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hf_ctx::Timed &t = ctx->timed[kind];
+    double sum = 0;
+    for (size_t i = 0; i < t.pending; ++i) {
+        float ms = 0;
+        HF_HIP(ctx, hipEventElapsedTime(&ms, t.ring[i].first, t.ring[i].second));
+        sum += ms;
+    }
+    *sum_ms = sum;
+    *launches = t.pending;
+    t.pending = 0;
+    return HF_OK;
+}
+
 const char *hf_last_error(const hf_ctx *ctx) { return ctx ? ctx->err : "no context"; }
 
 int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
@@ -2499,6 +2559,8 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
         ctx->hist_grid = (int)value;
     else if (!std::strcmp(name, "timeout_ms") && value > 0 && value <= 60000)
         ctx->timeout_ms = (int)value;
+    else if (!std::strcmp(name, "kernel_timing"))
+        ctx->kernel_timing = value != 0;
     else if (!std::strcmp(name, "dec_trace")) // device address, 128 bytes per segment; 0 = off
         ctx->dec_trace = reinterpret_cast<uint64_t *>((uintptr_t)value);
     else if (!std::strcmp(name, "debug") && value >= 0 && value < 512)
@@ -2523,8 +2585,9 @@ int hf_histogram_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d
     uint64_t want = (n + per_block - 1) / per_block;
     uint64_t cap = ctx->hist_grid > 0 ? (uint64_t)ctx->hist_grid : (uint64_t)ctx->num_cus * 4;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
-    hipLaunchKernelGGL(hist_kernel, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, d_in, n,
-                       reinterpret_cast<unsigned long long *>(d_hist));
+    HF_TIMED_LAUNCH(ctx, HF_TIMED_HISTOGRAM,
+                    hipLaunchKernelGGL(hist_kernel, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream,
+                                       d_in, n, reinterpret_cast<unsigned long long *>(d_hist)));
     HF_HIP(ctx, hipGetLastError());
     return HF_OK;
 }
@@ -2550,8 +2613,10 @@ int hf_histogram_batches_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uin
     uint64_t cap = ctx->hist_grid > 0 ? (uint64_t)ctx->hist_grid : (uint64_t)ctx->num_cus * 2;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(n_batches, cap));
     auto kern = ((uintptr_t)d_in & 15) == 0 ? hist_batches_kernel<true> : hist_batches_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, d_in, n,
-                       reinterpret_cast<unsigned long long *>(d_hist), d_batch_hist, n_batches);
+    HF_TIMED_LAUNCH(ctx, HF_TIMED_HISTOGRAM,
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, d_in,
+                                       n, reinterpret_cast<unsigned long long *>(d_hist),
+                                       d_batch_hist, n_batches));
     HF_HIP(ctx, hipGetLastError());
     return HF_OK;
 }
@@ -2830,7 +2895,12 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
                              : enc_pack_kernel<G, false, false, false>))
         kern = g == 4 ? HF_PICK(4) : (g == 2 ? HF_PICK(2) : HF_PICK(1));
 #undef HF_PICK
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), 0, ctx->stream, p);
+        // (only the launch over the complete batches is timed: the ragged rest is one workgroup)
+        if (lean)
+            HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE,
+                            hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), 0, ctx->stream, p));
+        else
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), 0, ctx->stream, p);
         if (chained && lean) // the follow-up launch numbers its own workgroups from zero again
             p.ticket += 1;
     }
@@ -3025,7 +3095,9 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
                     chunk_syms, lds);
     HF_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((uint32_t)n_segs), dim3(DEC_THREADS), lds, ctx->stream, p);
+    HF_TIMED_LAUNCH(ctx, HF_TIMED_DECODE,
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)n_segs), dim3(DEC_THREADS), lds,
+                                       ctx->stream, p));
     HF_HIP(ctx, hipGetLastError());
     return HF_OK;
 }

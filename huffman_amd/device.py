@@ -67,6 +67,15 @@ class Context:
     def synchronize(self) -> None:
         self.check(lib().hf_ctx_synchronize(self.handle))
 
+    def kernel_ms(self, kind: int) -> tuple[float, int]:
+        """Summed HIP-event duration and launch count of the dominant kernel of the
+        histogram (0), encode (1) or decode (2) calls since the last collection
+        (option "kernel_timing" must be on)."""
+        ms = C.c_double()
+        cnt = C.c_uint64()
+        self.check(lib().hf_ctx_kernel_ms(self.handle, kind, C.byref(ms), C.byref(cnt)))
+        return float(ms.value), int(cnt.value)
+
 
 def _check_u8(t: torch.Tensor) -> torch.Tensor:
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools_bench_matrix.sh <tag>  -- runs a few bench configurations, one JSON line each
 tag=$1
-for cfg in "--chunk-syms 64 --enc-mode 1" "--chunk-syms 64 --enc-mode 0" "--chunk-syms 128 --enc-mode 1" "--kind uniform" "--kind geometric" "--kind testfile"; do
+for cfg in "--chunk-syms 64" "--chunk-syms 64 --no-plan --enc-mode 1" "--chunk-syms 64 --no-plan --enc-mode 0" "--chunk-syms 128 --enc-mode 1" "--kind uniform" "--kind geometric" "--kind testfile"; do
   timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline $cfg 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
