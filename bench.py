@@ -90,9 +90,15 @@ def main():
     # HF_BENCH_FORCE_DIST=1 runs the collectives with a single rank too (a
     # rehearsal of the multi-GPU code path on a one-GPU box)
     use_dist = world > 1 or os.environ.get("HF_BENCH_FORCE_DIST") == "1"
+    json_fd = None
     if use_dist:
         import torch.distributed as dist  # noqa: F811
 
+        # RCCL prints a version banner on stdout when its first communicator
+        # comes up: everything but the result line goes to stderr instead
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=dev)
 
     gib = args.gib if args.gib is not None else 1.0
@@ -259,7 +265,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(data, args.cpu_sample_mib)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(result) + "\n").encode())
+        else:
+            print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
