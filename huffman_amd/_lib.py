@@ -80,6 +80,8 @@ SIGNATURES = {
     "hf_histogram_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
     "hf_encode_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                  C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, u64p]),
+    "hf_compress_host": (C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, u64p, u8p, C.c_uint64,
+                                   C.c_uint32, u16p, u64p, u64p]),
     "hf_decode_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                  C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hf_encoder_write_value_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p,

@@ -3298,6 +3298,92 @@ int hf_encode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
     return HF_OK;
 }
 
+int hf_compress_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n, uint64_t codes[256],
+                     uint64_t lens[256], uint8_t *h_out, uint64_t out_cap, uint32_t chunk_syms,
+                     uint16_t *h_chunk_bits, uint64_t *h_seg_off, uint64_t *total_bits)
+{
+    if (!ctx || !codes || !lens || !total_bits || (!h_in && n) || (!h_out && out_cap))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_compress_host: null pointer");
+    if ((h_chunk_bits == nullptr) != (h_seg_off == nullptr))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_compress_host: pass both gap arrays or neither");
+    if (n == 0)
+        return fail(ctx, HF_ERR_EMPTY, "hf_compress_host: empty input");
+    uint64_t n_chunks = 0, n_segs = 0;
+    if (h_chunk_bits && hf_gap_layout(n, chunk_syms, &n_chunks, &n_segs) != HF_OK)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_compress_host: chunk_syms must be 64, 128 or 256");
+    // A Huffman code never needs more than the 8 bits per symbol of the plain
+    // bytes, so n bytes (rounded up to the store width) always hold the stream.
+    // arena: input | histogram | batch histograms | stream | chunk_bits | seg_off
+    const uint64_t bound = std::min<uint64_t>((n + 15) & ~15ull, (out_cap + 3) & ~3ull);
+    const size_t off_hist = align_up(n + 16, 256);
+    const size_t off_bh = align_up(off_hist + 256 * 8, 256);
+    const size_t off_out = align_up(off_bh + hf_batch_hist_bytes(n), 256);
+    const size_t off_cb = align_up(off_out + bound + 16, 256);
+    const size_t off_so = align_up(off_cb + n_chunks * 2 + 16, 256);
+    const size_t total = off_so + n_segs * 8 + 16;
+    int rc = ensure_arena(ctx, total);
+    if (rc != HF_OK)
+        return rc;
+    uint8_t *a = static_cast<uint8_t *>(ctx->arena);
+    uint64_t *d_hist = reinterpret_cast<uint64_t *>(a + off_hist);
+    uint32_t *d_bh = reinterpret_cast<uint32_t *>(a + off_bh);
+    HF_HIP(ctx, hipMemcpyAsync(a, h_in, n, hipMemcpyHostToDevice, ctx->stream));
+    rc = hf_histogram_batches_async(ctx, a, n, d_hist, d_bh);
+    if (rc != HF_OK)
+        return rc;
+    uint64_t hist[256];
+    HF_HIP(ctx, hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = hf_build_codebook(hist, 256, codes, lens);
+    if (rc != HF_OK)
+        return fail(ctx, rc, "hf_compress_host: cannot build the codebook");
+    hf_model *model = nullptr;
+    rc = hf_model_create(ctx, codes, lens, &model);
+    if (rc != HF_OK)
+        return rc;
+    rc = hf_encode_planned_async(ctx, model, a, n, 0, d_bh, a + off_out,
+                                 std::min<uint64_t>(bound, out_cap), chunk_syms,
+                                 h_chunk_bits ? reinterpret_cast<uint16_t *>(a + off_cb) : nullptr,
+                                 h_seg_off ? reinterpret_cast<uint64_t *>(a + off_so) : nullptr,
+                                 ctx->d_result);
+    uint64_t res[HF_RES_WORDS] = {0};
+    if (rc == HF_OK) {
+        // the stream's length is known from the histogram: its download is
+        // queued behind the encoder without waiting for the result block
+        uint64_t bits = 0;
+        for (int i = 0; i < 256; ++i)
+            bits += hist[i] * lens[i];
+        const uint64_t nbytes = (bits + 7) / 8;
+        if (nbytes > out_cap) {
+            rc = fail(ctx, HF_ERR_CAPACITY, "hf_compress_host: output buffer too small");
+        } else {
+            hipError_t e = hipMemcpyAsync(h_out, a + off_out, nbytes, hipMemcpyDeviceToHost,
+                                          ctx->stream);
+            if (e == hipSuccess && h_chunk_bits && n_chunks) {
+                e = hipMemcpyAsync(h_chunk_bits, a + off_cb, n_chunks * 2, hipMemcpyDeviceToHost,
+                                   ctx->stream);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(h_seg_off, a + off_so, n_segs * 8, hipMemcpyDeviceToHost,
+                                       ctx->stream);
+            }
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(res, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost,
+                                   ctx->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess)
+                rc = fail(ctx, HF_ERR_HIP, "hf_compress_host: %s", hipGetErrorString(e));
+            else if ((rc = flags_to_status(ctx, res[HF_RES_FLAGS])) == HF_OK &&
+                     res[HF_RES_TOTAL_BITS] != bits)
+                rc = fail(ctx, HF_ERR_INTERNAL, "hf_compress_host: stream length mismatch");
+            *total_bits = bits;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    hf_model_destroy(model);
+    return rc;
+}
+
 int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint64_t in_bytes,
                    uint64_t n_out, uint32_t chunk_syms, const uint16_t *h_chunk_bits,
                    const uint64_t *h_seg_off, uint8_t *h_out)

@@ -268,6 +268,18 @@ HF_API int hf_encode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_i
                           uint32_t lead_bits, uint8_t *h_out, uint64_t out_cap,
                           uint32_t chunk_syms, uint16_t *h_chunk_bits, uint64_t *h_seg_off,
                           uint64_t *total_bits);
+/* Huffman::from_reader followed by Encoder::write over the same bytes and
+ * Encoder::flush -- what stream_compress_with_header_information does with a
+ * file between the header and the end (src/lib.rs:36-37 and 68-79) -- for a
+ * host slice, with a single upload: counting pass with batch histograms,
+ * codebook on the host (returned in codes/lens, src/huffman/mod.rs:181-206),
+ * planned encode, download.  out_cap >= n always suffices (a Huffman code
+ * needs at most the 8 bits per symbol of the plain bytes); n == 0 is
+ * HF_ERR_EMPTY as in the reference (mod.rs:72-73). */
+HF_API int hf_compress_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n, uint64_t codes[256],
+                            uint64_t lens[256], uint8_t *h_out, uint64_t out_cap,
+                            uint32_t chunk_syms, uint16_t *h_chunk_bits, uint64_t *h_seg_off,
+                            uint64_t *total_bits);
 HF_API int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in,
                           uint64_t in_bytes, uint64_t n_out, uint32_t chunk_syms,
                           const uint16_t *h_chunk_bits, const uint64_t *h_seg_off,

@@ -793,6 +793,49 @@ inline void stream_compress_with_header_information(const std::string &source,
                                                     const std::string &destination)
 {
     FileReader reader(source);
+    {
+        // A file that fits one staging buffer goes to the device once: counting
+        // pass, codebook, planned encode and download in a single call.  The
+        // bytes written are the same as on the general path below.
+        std::ifstream sz(source, std::ios::binary | std::ios::ate);
+        const std::uint64_t size = sz ? (std::uint64_t)sz.tellg() : 0;
+        if (size > 0 && size <= huffman::encode::Encoder<FileWriter>::STAGE_LIMIT) {
+            std::vector<u8> data(size);
+            if (reader.read(data.data(), size) != size)
+                throw IoError(false, "failed to read the source file");
+            std::array<usize, 256> codes{}, lens{};
+            std::vector<u8> stream(size + 16);
+            huffman::GapArray gap;
+            gap.chunk_syms = 64;
+            gap.symbols = size;
+            std::uint64_t nc = 0, ns = 0;
+            Runtime::check(hf_gap_layout(size, gap.chunk_syms, &nc, &ns), "gap layout");
+            gap.chunk_bits.resize(nc);
+            gap.seg_off.resize(ns);
+            std::uint64_t bits = 0;
+            Runtime::check(hf_compress_host(Runtime::ctx(), data.data(), size, codes.data(),
+                                            lens.data(), stream.data(), stream.size(),
+                                            gap.chunk_syms, gap.chunk_bits.data(),
+                                            gap.seg_off.data(), &bits),
+                           "stream_compress");
+            const huffman::Huffman h(codes, lens);
+            huffman::header::Header hd;
+            hd.magic = {'p', 'z', 'h', 'f'}; // Encoder::magic, encode.rs:51-53
+            hd.btree = h.to_btreemap();
+            hd.sentinel = h.sentinel();
+            hd.update_readbytes(size); // lib.rs:52-53
+            const auto header = hd.to_binary();
+            const auto header_length = u64_to_bytes(header.size());
+            FileWriter out(destination);
+            out.write(hd.magic.data(), hd.magic.size());
+            out.write(header_length.data(), 8);
+            out.write(header.data(), header.size());
+            out.write(stream.data(), (bits + 7) / 8);
+            out.flush();
+            write_gap_sidecar(gap_sidecar_path(destination), gap);
+            return;
+        }
+    }
     std::vector<u8> buffer(BUF);
     auto h = huffman::Huffman::from_reader(reader);
     huffman::encode::Encoder<FileWriter> writer(FileWriter(destination), h);

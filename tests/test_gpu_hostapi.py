@@ -165,3 +165,44 @@ def test_cli_headerless_stream_and_argument_errors(tmp_path, orc):
     assert run_cli(str(src), str(dst), "h").returncode == 101
     assert run_cli(str(src), str(dst), "h", "q").returncode == 101
     assert run_cli(str(tmp_path / "missing"), str(dst), "h", "c").returncode == 101
+
+
+@pytest.mark.parametrize("kind,n", [("zipf", 1), ("testfile", 65536), ("geometric", 300001),
+                                    ("uniform", (1 << 21) + 5)])
+def test_compress_host_single_upload(ctx, orc, kind, n):
+    """from_reader + write + flush in one call: same codebook, stream and gap
+    array as the separate host entry points (and the oracle)."""
+    L = _lib.lib()
+    data = synth.generate_host(kind, n, seed=n + 3)
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    out = np.zeros(n + 16, dtype=np.uint8)
+    nc, ns = C.c_uint64(), C.c_uint64()
+    assert L.hf_gap_layout(n, 64, C.byref(nc), C.byref(ns)) == _lib.HF_OK
+    cb = np.zeros(max(nc.value, 1), dtype=np.uint16)
+    so = np.zeros(max(ns.value, 1), dtype=np.uint64)
+    bits = C.c_uint64()
+    rc = L.hf_compress_host(ctx, data.ctypes.data_as(u8p), n, codes.ctypes.data_as(u64p),
+                            lens.ctypes.data_as(u64p), out.ctypes.data_as(u8p), out.size, 64,
+                            cb.ctypes.data_as(u16p), so.ctypes.data_as(u64p), C.byref(bits))
+    assert rc == _lib.HF_OK, L.hf_last_error(ctx)
+    wc, wl = orc.generate_extended_codewords(orc.histogram(data))
+    assert np.array_equal(codes, wc) and np.array_equal(lens, wl)
+    want, _ = orc.encode_slice(data, wc, wl)
+    nbytes = (bits.value + 7) // 8
+    assert nbytes == want.size and np.array_equal(out[:nbytes], want)
+    l = np.asarray(wl, dtype=np.uint64)[data]
+    pad = np.zeros(nc.value * 64, dtype=np.uint64)
+    pad[:n] = l
+    assert np.array_equal(cb[: nc.value].astype(np.uint64), pad.reshape(-1, 64).sum(axis=1))
+    # too small an output buffer and an empty input are reported, not written
+    small = np.zeros(8, dtype=np.uint8)
+    if want.size > 8:
+        rc = L.hf_compress_host(ctx, data.ctypes.data_as(u8p), n, codes.ctypes.data_as(u64p),
+                                lens.ctypes.data_as(u64p), small.ctypes.data_as(u8p), small.size,
+                                64, None, None, C.byref(bits))
+        assert rc == _lib.HF_ERR_CAPACITY
+    rc = L.hf_compress_host(ctx, data.ctypes.data_as(u8p), 0, codes.ctypes.data_as(u64p),
+                            lens.ctypes.data_as(u64p), out.ctypes.data_as(u8p), out.size, 64,
+                            None, None, C.byref(bits))
+    assert rc == _lib.HF_ERR_EMPTY

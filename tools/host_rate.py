@@ -75,11 +75,36 @@ def main():
         dec.append(time.perf_counter() - t0)
         assert rc == 0
     assert torch.equal(back_t, data_t)
+    # the whole compress pipeline: separate calls (two uploads) against the fused one
+    sep, fused = [], []
+    c2 = np.zeros(256, dtype=np.uint64)
+    l2 = np.zeros(256, dtype=np.uint64)
+    for _ in range(a.reps):
+        t0 = time.perf_counter()
+        assert L.hf_histogram_host(ctx, C.cast(data_t.data_ptr(), u8p), n, hist.ctypes.data_as(u64p)) == 0
+        assert L.hf_build_codebook(hist.ctypes.data_as(u64p), 256, c2.ctypes.data_as(u64p),
+                                   l2.ctypes.data_as(u64p)) == 0
+        m2 = C.c_void_p()
+        assert L.hf_model_create(ctx, c2.ctypes.data_as(u64p), l2.ctypes.data_as(u64p), C.byref(m2)) == 0
+        assert L.hf_encode_host(ctx, m2, C.cast(data_t.data_ptr(), u8p), n, 0,
+                                C.cast(out_t.data_ptr(), u8p), cap, 64,
+                                C.cast(cb_t.data_ptr(), u16p), C.cast(so_t.data_ptr(), u64p),
+                                C.byref(bits)) == 0
+        L.hf_model_destroy(m2)
+        sep.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        assert L.hf_compress_host(ctx, C.cast(data_t.data_ptr(), u8p), n, c2.ctypes.data_as(u64p),
+                                  l2.ctypes.data_as(u64p), C.cast(out_t.data_ptr(), u8p), cap, 64,
+                                  C.cast(cb_t.data_ptr(), u16p), C.cast(so_t.data_ptr(), u64p),
+                                  C.byref(bits)) == 0
+        fused.append(time.perf_counter() - t0)
     print(json.dumps({
         "workload": f"{a.mib} MiB {a.kind}, host buffers {'pinned' if a.pinned else 'pageable'}",
         "histogram_host_GBps": round(n / t_hist / 1e9, 2),
         "encode_host_GBps": round(n / min(enc) / 1e9, 2),
         "decode_host_GBps": round(n / min(dec) / 1e9, 2),
+        "compress_separate_calls_GBps": round(n / min(sep) / 1e9, 2),
+        "compress_host_GBps": round(n / min(fused) / 1e9, 2),
         "compressed_ratio": round(nbytes / n, 4),
     }))
     L.hf_model_destroy(model)
