@@ -700,9 +700,11 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
 // total, which kernel 2 scans: 8 times fewer entries for its single workgroup.
 __global__ __launch_bounds__(ENC_THREADS) void enc_plan_bits_kernel(
     const uint32_t *__restrict__ batch_hist, const uint8_t *__restrict__ len8,
-    uint64_t *group_off, uint32_t *local, uint32_t *tot, uint32_t n_batches)
+    uint64_t *group_off, uint32_t *local, uint32_t *tot, uint32_t n_batches, uint64_t *result)
 {
     __shared__ uint32_t s_tot[ENC_WAVES];
+    if (blockIdx.x == 0 && threadIdx.x < HF_RES_WORDS)
+        result[threadIdx.x] = 0; // first kernel of a planned encode: no separate memset
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * ENC_WAVES + wv;
     uint32_t sum = 0; // at most 65536 symbols of at most 57 bits
@@ -2803,7 +2805,8 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: chunk_syms must be 64, 128 or 256");
     if (n >= (1ull << 45))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: n too large");
-    HF_HIP(ctx, hipMemsetAsync(d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
+    if (!d_batch_hist || n == 0) // (the planned path's first kernel clears the block itself)
+        HF_HIP(ctx, hipMemsetAsync(d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
     if (n == 0) {
         const uint64_t bytes = (lead_bits + 7) / 8;
         if (bytes > out_cap)
@@ -2861,7 +2864,7 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         uint32_t *local = reinterpret_cast<uint32_t *>(off + n_groups + 1);
         uint32_t *tot = local + n_batches;
         hipLaunchKernelGGL(enc_plan_bits_kernel, dim3(n_groups), dim3(ENC_THREADS), 0, ctx->stream,
-                           d_batch_hist, model->d_len8, off, local, tot, n_batches);
+                           d_batch_hist, model->d_len8, off, local, tot, n_batches, d_result);
         hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, off,
                            n_groups, d_result);
         p.plan_off = off;
