@@ -220,7 +220,9 @@ def main():
     roofline = {
         "bound": "hbm",
         "kernel": {"encode": "enc_pack_kernel",
-                   "decode": "dec_kernel_reg" if cs == 64 else "dec_kernel"}[dom],
+                   # (larger chunks of a model whose table needs a second level take dec_kernel)
+                   "decode": "dec_kernel_reg" if cs == 64 or int(state["lens"].max()) <= 11
+                   else "dec_kernel"}[dom],
         "achieved": round(kernels[dom]["GBps"], 1),
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",

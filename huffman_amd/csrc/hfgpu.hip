@@ -3047,7 +3047,8 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     void (*kern)(DecParams) = nullptr;
     size_t lds = 0;
     const bool reg128 = chunk_syms == 128 && !model->lut_escapes;
-    if ((chunk_syms == 64 || reg128) && !(ctx->debug & 256)) {
+    const bool reg256 = chunk_syms == 256 && !model->lut_escapes;
+    if ((chunk_syms == 64 || reg128 || reg256) && !(ctx->debug & 256)) {
         // register-output kernel: one LDS image serves as input, then as output
         const uint32_t in_raw = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
         const uint32_t in_words = in_raw + in_raw / 32 + 1; // padded slots, see SwzWords
@@ -3056,7 +3057,13 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
         lds = lut_bytes + (size_t)(p.istg_words + 4) * 4;
         // symbols per window rebuild: K * sentinel <= 64, or the model's speculative K
         const uint32_t k = 64u / std::max<uint32_t>(model->sentinel, 1u);
-        if (reg128)
+        if (reg256) // 64 output registers per lane, two work-groups per CU
+            kern = model->regular_chunks
+                       ? (k >= 6 ? dec_kernel_reg<256, 6, false, true, false>
+                                 : dec_kernel_reg<256, 5, false, true, false>)
+                       : (k >= 6 ? dec_kernel_reg<256, 6, false, false, false>
+                                 : dec_kernel_reg<256, 5, false, false, false>);
+        else if (reg128)
             kern = model->regular_chunks
                        ? (k >= 6 ? dec_kernel_reg<128, 6, false, true, false>
                                  : dec_kernel_reg<128, 5, false, true, false>)
