@@ -319,10 +319,15 @@ uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t
     }
     for (double &x : d)
         x /= kraft;
-    // P(sum of lengths = a) after 8 and after 16 codes, everything above 64 in c[65]
+    // P(sum of lengths = a) after 6, 7, 8 and 16 codes, everything above 64 in c[65]
     double c[66] = {0};
     c[0] = 1.0;
-    double over[2] = {1.0, 1.0};
+    const uint32_t widths[4] = {16u, 8u, 7u, 6u};
+    // a chunk in ten million may hold an overflowing group of 16 or 8 codes, one
+    // in a hundred thousand a group of 7 or 6 (the gain per window is smaller,
+    // but so is the work that a lane which has to decode again repeats)
+    const double limit[4] = {1e-7, 1e-7, 1e-5, 1e-5};
+    double over[4] = {1.0, 1.0, 1.0, 1.0};
     int lo = 0, hi = 0; // sums that can occur so far (below the overflow bin)
     int minlen = 64, maxl = 0;
     for (int q = 0; q < np; ++q)
@@ -338,21 +343,19 @@ uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t
         }
         std::memcpy(c, nc, sizeof(c));
         lo = std::min(lo + minlen, 64), hi = std::min(hi + maxl, 64);
-        if (i == 8) {
-            over[1] = c[65];
-            // 16 codes overflow at least as often as 8: nothing left to find
-            if (1.0 - std::pow(1.0 - over[1], 8.0) > 1e-7)
-                return 0;
-        }
-        if (i == 16)
-            over[0] = c[65];
+        for (int t = 0; t < 4; ++t)
+            if (widths[t] == i)
+                over[t] = c[65];
+        // more codes overflow at least as often: once the most lenient test
+        // fails for this many codes, nothing wider can pass
+        if (i >= 6 && 1.0 - std::pow(1.0 - c[65], 64.0 / i) > 1e-5)
+            break;
     }
-    const uint32_t widths[2] = {16u, 8u};
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 4; ++t) {
         if (widths[t] * sentinel <= 64)
             continue;
         const double p_chunk = 1.0 - std::pow(1.0 - over[t], 64.0 / widths[t]);
-        if (p_chunk <= 1e-7)
+        if (p_chunk <= limit[t])
             return widths[t];
     }
     return 0;

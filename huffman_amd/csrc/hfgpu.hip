@@ -2233,7 +2233,7 @@ struct hf_model {
     bool has_encode = false;
     bool lut_escapes = false; // the decode table holds entries with the escape bit
     bool regular_chunks = false; // 64 symbols are expected to differ by < 8 bits in length
-    uint32_t dec_spec_k = 0; // 16 or 8: codes per 64-bit window the decoder may assume (else 0)
+    uint32_t dec_spec_k = 0; // 16, 8, 7 or 6: codes per 64-bit window the decoder may assume (else 0)
     hipStream_t use_stream = nullptr; // the tables were uploaded on this stream ...
     hipEvent_t ready = nullptr;       // ... and are complete once this event has passed
     mutable bool foreign = false;     // kernels on other streams have used the tables
@@ -3069,13 +3069,18 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
                                  : dec_kernel_reg<128, 5, false, true, false>)
                        : (k >= 6 ? dec_kernel_reg<128, 6, false, false, false>
                                  : dec_kernel_reg<128, 5, false, false, false>);
-        else if (model->dec_spec_k >= 8 && model->dec_spec_k > k) {
+        else if (model->dec_spec_k > k) {
+            const uint32_t sk = model->dec_spec_k;
             if (model->lut_escapes)
-                kern = model->dec_spec_k >= 16 ? dec_kernel_reg<64, 16, true, false, true>
-                                               : dec_kernel_reg<64, 8, true, false, true>;
+                kern = sk >= 16 ? dec_kernel_reg<64, 16, true, false, true>
+                                : (sk >= 8 ? dec_kernel_reg<64, 8, true, false, true>
+                                           : (sk == 7 ? dec_kernel_reg<64, 7, true, false, true>
+                                                      : dec_kernel_reg<64, 6, true, false, true>));
             else
-                kern = model->dec_spec_k >= 16 ? dec_kernel_reg<64, 16, false, false, true>
-                                               : dec_kernel_reg<64, 8, false, false, true>;
+                kern = sk >= 16 ? dec_kernel_reg<64, 16, false, false, true>
+                                : (sk >= 8 ? dec_kernel_reg<64, 8, false, false, true>
+                                           : (sk == 7 ? dec_kernel_reg<64, 7, false, false, true>
+                                                      : dec_kernel_reg<64, 6, false, false, true>));
         } else if (model->lut_escapes)
             kern = k >= 4 ? dec_kernel_reg<64, 4, true, false, false>
                           : (k == 3 ? dec_kernel_reg<64, 3, true, false, false>

@@ -41,12 +41,13 @@ int model_table(const uint64_t codes[256], const uint64_t lens[256], uint64_t ke
 // than one wave in a thousand has such a lane; `speculative` says whether a
 // group can overflow at all.
 int pick_merge_width(const uint64_t lens[256], bool *speculative);
-// Codes the decoder may take from one 64-bit window without checking, 16 or 8,
-// or 0 when only sentinel-many bits per code are safe.  Only for models that
-// are prefix free (a code that fits the window then decodes the same whatever
-// follows it): the largest of the two for which, with symbols drawn with the
-// probabilities 2^-len that the lengths imply, fewer than one chunk of 64
-// symbols in ten million holds a group that exceeds 64 bits.
+// Codes the decoder may take from one 64-bit window without checking (16, 8, 7
+// or 6), or 0 when only sentinel-many bits per code are safe.  Only for models
+// that are prefix free (a code that fits the window then decodes the same
+// whatever follows it): the largest width for which, with symbols drawn with
+// the probabilities 2^-len that the lengths imply, fewer than one chunk of 64
+// symbols in ten million (16, 8) or in a hundred thousand (7, 6) holds a group
+// that exceeds 64 bits.
 uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t m,
                             uint32_t sentinel);
 int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *klens, uint64_t m,
