@@ -10,7 +10,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhfgpu.so")
 SOURCES = [os.path.join(CSRC, "hfgpu.hip"), os.path.join(CSRC, "codebook.cpp")]
-HEADERS = [os.path.join(ROOT, "include", "hfgpu.h"), os.path.join(CSRC, "hfgpu_internal.h")]
+HEADERS = [os.path.join(ROOT, "include", "hfgpu.h"), os.path.join(CSRC, "hfgpu_internal.h")] + [
+    os.path.join(CSRC, h) for h in ("dev_common.hpp", "kern_hist.hpp", "kern_encode.hpp",
+                                    "kern_decode.hpp", "kern_gap.hpp")]
 # host programs on top of the C++ mirror (include/hfgpu.hpp): (source, executable)
 PROGRAMS = [
     (os.path.join(HERE, "cli", "main.cpp"), os.path.join(HERE, "bin", "hfgpu")),

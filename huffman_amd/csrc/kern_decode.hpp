@@ -1,0 +1,641 @@
+// Decoder kernels (src/huffman/decode/mod.rs:70-231).
+// Part of the single translation unit huffman_amd/csrc/hfgpu.hip (device code
+// for gfx950, wave64); included there, not compiled on its own.
+#ifndef HFGPU_KERN_DECODE_HPP
+#define HFGPU_KERN_DECODE_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "hfgpu.h"
+#include "dev_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------- decode
+//
+// One workgroup decodes one segment = 256 chunks; lane l decodes chunk l
+// (chunk_syms symbols) sequentially.  The chunk start bits come from the gap
+// array: the segment's absolute start plus a workgroup scan of the 16-bit
+// chunk lengths.  The segment's compressed bytes are staged once, with
+// coalesced 16-byte loads, byte-swapped into an LDS image of big-endian
+// words, and the decoded bytes are collected in a padded LDS image and
+// written out with coalesced 16-byte stores, so global memory only sees
+// whole-line traffic although every lane walks its own bit stream.
+// Symbols are resolved through the LDS-resident multi-level table; the rare
+// slots that the table cannot resolve fall back to a predecessor search over
+// the sorted keys with the full sentinel-wide window.
+
+constexpr int DEC_THREADS = 256;
+
+struct DecParams {
+    const uint8_t *in;
+    uint64_t in_bytes;
+    uint64_t bit_base;
+    uint64_t n_out;
+    uint64_t n_chunks;
+    uint32_t chunk_syms;
+    const uint16_t *chunk_bits;
+    const uint64_t *seg_off;
+    uint8_t *out;
+    uint64_t *result;
+    const uint16_t *lut;
+    uint32_t lut_entries;
+    uint32_t w1;
+    uint32_t sentinel;
+    const uint64_t *keys;
+    const uint8_t *ksyms;
+    const uint8_t *klens;
+    uint32_t m;
+    uint32_t istg_words;
+    uint32_t in_aligned16;
+    uint32_t out_aligned16;
+    uint64_t *trace; // HF_DEC_TRACE builds: 16 stamps per segment, or null
+};
+
+// Big-endian 32-bit word `w` of the compressed buffer; bytes past the end are 0.
+__device__ __forceinline__ uint32_t dec_load_word(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                  uint64_t w)
+{
+    const uint64_t b = w << 2;
+    if (b + 4 <= in_bytes)
+        return bswap32(*reinterpret_cast<const uint32_t *>(in + b));
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (b + i < in_bytes)
+            v |= (uint32_t)in[b + i] << (24 - 8 * i);
+    return v;
+}
+
+struct LdsWords {
+    const uint32_t *w;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return w[i]; }
+};
+// LDS image with one unused slot after every 32 words, for streams whose
+// chunks all have (nearly) the same size -- 16 words for 8-bit codes: without
+// the padding all lanes of a wave would start on the same two banks.  Costs two
+// instructions per word read, so irregular streams keep the plain layout.
+struct SwzWords {
+    const uint32_t *w;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return w[i + (i >> 5)]; }
+};
+struct GlobalWords {
+    const uint8_t *in;
+    uint64_t in_bytes;
+    uint64_t wbase;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const
+    {
+        return dec_load_word(in, in_bytes, wbase + i);
+    }
+};
+
+// Largest key <= v among the sorted keys, or -1.
+__device__ __forceinline__ int dec_predecessor(const uint64_t *keys, uint32_t m, uint64_t v)
+{
+    int lo = 0, hi = (int)m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] <= v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo - 1;
+}
+
+template <typename Src>
+__device__ __forceinline__ uint64_t dec_peek64(const Src &src, uint32_t pos)
+{
+    const uint32_t w = pos >> 5, o = pos & 31u;
+    const uint64_t hi = ((uint64_t)src(w) << 32) | src(w + 1);
+    return o ? (hi << o) | ((uint64_t)src(w + 2) >> (32 - o)) : hi;
+}
+
+// MSB-first bit reader over 32-bit words.  The word after the ones already
+// merged into `buf` is kept in a register (`nxt`), so a refill never waits for
+// memory: it merges the register and issues the load of the following word.
+template <typename Src>
+struct BitReader {
+    const Src &src;
+    uint64_t buf; // unread bits, left aligned, zeros below
+    int32_t bits; // number of valid bits in buf
+    uint32_t wp;  // index of the word after nxt
+    uint32_t nxt; // prefetched word wp - 1
+    __device__ __forceinline__ BitReader(const Src &s, uint32_t pos) : src(s) { seek(pos); }
+    __device__ __forceinline__ void seek(uint32_t pos)
+    {
+        const uint32_t w = pos >> 5, o = pos & 31u;
+        buf = (((uint64_t)src(w) << 32) | src(w + 1)) << o;
+        bits = 64 - (int32_t)o;
+        nxt = src(w + 2);
+        wp = w + 3;
+    }
+    __device__ __forceinline__ uint32_t pos() const { return (wp - 1) * 32u - (uint32_t)bits; }
+    __device__ __forceinline__ void refill()
+    {
+        if (bits <= 32) {
+            buf |= (uint64_t)nxt << (32 - bits);
+            bits += 32;
+            nxt = src(wp);
+            ++wp;
+        }
+    }
+};
+
+// Resolves a table entry with the escape bit set: walks the sub-tables, then
+// falls back to the predecessor search.  Consumes the symbol's bits itself.
+template <typename Src>
+__device__ inline uint32_t dec_escape(BitReader<Src> &br, uint32_t e, const uint16_t *s_lut,
+                                            const DecParams &p, bool &bad)
+{
+    const uint32_t hi = (uint32_t)(br.buf >> 32);
+    uint32_t used = p.w1;
+    while ((e & 0x8000u) && e < HF_LUT_INVALID) {
+        const uint32_t idx = (hi << used) >> (32 - HF_LUT_W2);
+        e = s_lut[(1u << p.w1) + ((e & 0x7fffu) << HF_LUT_W2) + idx];
+        used += HF_LUT_W2;
+    }
+    if (e < HF_LUT_INVALID) {
+        const uint32_t len = e >> 8;
+        br.buf <<= len;
+        br.bits -= (int32_t)len;
+        return e & 0xffu;
+    }
+    if (e == HF_LUT_SEARCH) {
+        const uint32_t pos = br.pos();
+        const uint64_t window = dec_peek64(br.src, pos) >> (64 - p.sentinel);
+        const int k = dec_predecessor(p.keys, p.m, window);
+        uint32_t sym = 0, len = 0;
+        if (k >= 0) {
+            sym = p.ksyms[k];
+            len = p.klens[k];
+        } else {
+            bad = true;
+        }
+        br.seek(pos + len);
+        br.refill();
+        return sym;
+    }
+    bad = true; // window below the smallest key
+    return 0;
+}
+
+// One symbol.  Needs >= 32 valid bits (or >= sentinel bits when the model's
+// sentinel is <= 16) in the reader.  ESC = the table contains escape entries.
+template <typename Src, bool ESC>
+__device__ __forceinline__ uint32_t dec_symbol(BitReader<Src> &br, const uint16_t *s_lut,
+                                               uint32_t shift, const DecParams &p, bool &bad)
+{
+    const uint32_t e = s_lut[(uint32_t)(br.buf >> 32) >> shift];
+    if (ESC && __builtin_expect(e & 0x8000u, 0))
+        return dec_escape(br, e, s_lut, p, bad);
+    const uint32_t len = e >> 8;
+    br.buf <<= len;
+    br.bits -= (int32_t)len;
+    return e & 0xffu;
+}
+
+template <typename Src, int SPR, bool ESC>
+__device__ __forceinline__ void dec_lane(const Src &src, uint32_t startbit, uint32_t cnt,
+                                         const uint16_t *s_lut, const DecParams &p,
+                                         uint32_t *orow, bool &bad)
+{
+    BitReader<Src> br(src, startbit);
+    const uint32_t shift = 32 - p.w1;
+    uint32_t i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+        uint32_t pack = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((k % SPR) == 0)
+                br.refill();
+            pack |= dec_symbol<Src, ESC>(br, s_lut, shift, p, bad) << (8 * k);
+        }
+        orow[i >> 2] = pack;
+    }
+    if (i < cnt) {
+        uint32_t pack = 0;
+        for (uint32_t k = 0; i + k < cnt; ++k) {
+            br.refill();
+            pack |= dec_symbol<Src, ESC>(br, s_lut, shift, p, bad) << (8 * k);
+        }
+        orow[i >> 2] = pack;
+    }
+}
+
+template <int SPR, bool ESC>
+__global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t lut_bytes = (p.lut_entries * 2u + 15u) & ~15u;
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *istg = reinterpret_cast<uint32_t *>(smem + lut_bytes);
+    uint32_t *ostg = istg + p.istg_words;
+    const uint32_t cs = p.chunk_syms;
+    const uint32_t orow_words = cs / 4 + 1; // +1: lanes start on different banks
+    uint32_t *s_wave = ostg + HF_SEG_CHUNKS * orow_words;
+
+    const uint64_t seg = blockIdx.x;
+    const uint64_t c = seg * HF_SEG_CHUNKS + threadIdx.x;
+    const bool valid = c < p.n_chunks;
+    const uint32_t cb = valid ? p.chunk_bits[c] : 0u;
+    // table: 16-byte loads (the table starts 16-byte aligned in device memory)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.lut);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < lut_bytes / 16; i += DEC_THREADS)
+            dst[i] = src[i];
+    }
+    uint32_t total;
+    const uint32_t excl = block_excl_scan256(cb, s_wave, total);
+    const uint64_t seg_start = p.seg_off[seg] - p.bit_base;
+    // the image starts at the 16-byte unit that holds the segment's first bit
+    const uint64_t ubase = seg_start >> 7;
+    const uint32_t s_lo = (uint32_t)(seg_start & 127u);
+    const uint32_t nunits = (s_lo + total + 127u) / 128u + 1u; // +1: readers run ahead
+    const bool use_lds = nunits * 4u <= p.istg_words;
+    if (use_lds) {
+        uint4 *dst = reinterpret_cast<uint4 *>(istg);
+        const uint64_t whole = p.in_bytes >> 4; // units that lie fully inside the buffer
+        if (p.in_aligned16) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.in);
+            for (uint32_t i = threadIdx.x; i < nunits; i += DEC_THREADS) {
+                const uint64_t u = ubase + i;
+                uint4 v;
+                if (u < whole) {
+                    v = src[u];
+                    v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
+                } else {
+                    v.x = dec_load_word(p.in, p.in_bytes, u * 4 + 0);
+                    v.y = dec_load_word(p.in, p.in_bytes, u * 4 + 1);
+                    v.z = dec_load_word(p.in, p.in_bytes, u * 4 + 2);
+                    v.w = dec_load_word(p.in, p.in_bytes, u * 4 + 3);
+                }
+                dst[i] = v;
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < nunits * 4u; i += DEC_THREADS)
+                istg[i] = dec_load_word(p.in, p.in_bytes, ubase * 4 + i);
+        }
+    }
+    __syncthreads();
+
+    const uint64_t sym0 = c * cs;
+    const uint32_t cnt = valid ? (uint32_t)min((uint64_t)cs, p.n_out - sym0) : 0u;
+    bool bad = false;
+    if (cnt) {
+        uint32_t *orow = ostg + threadIdx.x * orow_words;
+        if (use_lds) {
+            LdsWords src{istg};
+            dec_lane<LdsWords, SPR, ESC>(src, s_lo + excl, cnt, s_lut, p, orow, bad);
+        } else {
+            GlobalWords src{p.in, p.in_bytes, ubase * 4};
+            dec_lane<GlobalWords, 1, true>(src, s_lo + excl, cnt, s_lut, p, orow, bad);
+        }
+    }
+    if (bad)
+        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
+    __syncthreads();
+
+    const uint64_t obase = seg * HF_SEG_CHUNKS * (uint64_t)cs;
+    const uint64_t oleft = p.n_out - obase;
+    const uint32_t seg_len = (uint32_t)min(oleft, (uint64_t)HF_SEG_CHUNKS * cs);
+    for (uint32_t o = threadIdx.x * 16u; o < seg_len; o += DEC_THREADS * 16u) {
+        const uint32_t ch = o / cs, within = o % cs;
+        const uint32_t *srcw = ostg + ch * orow_words + within / 4;
+        uint4 v;
+        v.x = srcw[0];
+        v.y = srcw[1];
+        v.z = srcw[2];
+        v.w = srcw[3];
+        if (o + 16u <= seg_len && p.out_aligned16) {
+            *reinterpret_cast<uint4 *>(p.out + obase + o) = v;
+        } else {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t i = 0; i < 16u && o + i < seg_len; ++i)
+                p.out[obase + o + i] = (uint8_t)(vv[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
+// Escape entry `e` of the first level resolved from a 64-bit window whose
+// top `sentinel` bits are valid: walks the sub-tables, then falls back to the
+// predecessor search.  Returns a plain entry (len << 8 | sym); len 0 and
+// `bad` set when the window lies below the smallest key.
+__device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uint16_t *s_lut,
+                                             const DecParams &p, bool &bad)
+{
+    const uint32_t hi = (uint32_t)(win >> 32);
+    uint32_t used = p.w1;
+    while ((e & 0x8000u) && e < HF_LUT_INVALID) {
+        const uint32_t idx = (hi << used) >> (32 - HF_LUT_W2);
+        e = s_lut[(1u << p.w1) + ((e & 0x7fffu) << HF_LUT_W2) + idx];
+        used += HF_LUT_W2;
+    }
+    if (e < HF_LUT_INVALID)
+        return e;
+    if (e == HF_LUT_SEARCH) {
+        const int k = dec_predecessor(p.keys, p.m, win >> (64 - p.sentinel));
+        if (k >= 0)
+            return ((uint32_t)p.klens[k] << 8) | p.ksyms[k];
+    }
+    bad = true;
+    return 0;
+}
+
+// Register-output form of the decode kernel for 64-symbol chunks.  ESC = the
+// model's table has escape entries (codes longer than the first-level index).
+// A lane keeps its CS decoded bytes in CS/4 registers (the symbol loop is
+// fully unrolled), so the LDS image of the compressed words can be reused for
+// the output once every lane has finished reading it: a workgroup needs
+// max(input, output) bytes of LDS instead of their sum, which nearly doubles
+// the number of resident workgroups -- and decoding is bound by the latency of
+// its dependent table lookups, i.e. by the number of chunks in flight.
+// Lanes whose chunk is ragged (end of the stream) and segments too dense for
+// the image take a rolled loop that stores bytes straight to global memory.
+// Built with -DHF_DEC_TRACE (HF_DEC_TRACE=1 python huffman_amd/build.py) and
+// given a buffer through the context option "dec_trace", threads 0 and 192 of
+// every work-group stamp the wall clock at the phase boundaries of the decode
+// kernel (8 stamps each per segment); tools/trace_dec.py prints the timeline.
+#ifdef HF_DEC_TRACE
+#define DEC_TRACE(i)                                                                          \
+    do {                                                                                      \
+        if (trp)                                                                              \
+            trp[(i)] = wall_clock64();                                                        \
+    } while (0)
+#else
+#define DEC_TRACE(i)                                                                          \
+    do {                                                                                      \
+    } while (0)
+#endif
+template <int CS, int K, bool ESC, bool SWZ, bool SPEC>
+__global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr uint32_t OROW = CS / 4 + 1; // +1: lanes start on different banks
+    using Img = typename std::conditional<SWZ, SwzWords, LdsWords>::type;
+    const uint32_t lut_bytes = (p.lut_entries * 2u + 15u) & ~15u;
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *img = reinterpret_cast<uint32_t *>(smem + lut_bytes); // input, then output
+    uint32_t *s_wave = img + p.istg_words;
+
+    const uint64_t seg = blockIdx.x;
+#ifdef HF_DEC_TRACE
+    uint64_t *trp = (p.trace && (threadIdx.x == 0 || threadIdx.x == 192))
+                        ? p.trace + seg * 16 + (threadIdx.x ? 8 : 0)
+                        : nullptr;
+#endif
+    DEC_TRACE(0);
+    // The segment's span of the stream is known from the segment offsets
+    // alone (this one's and the next one's), so its first 16 KiB are requested
+    // before anything else: one memory latency covers them, the gap array and
+    // the table, instead of two in a row.
+    const uint64_t c = seg * HF_SEG_CHUNKS + threadIdx.x;
+    const bool valid = c < p.n_chunks;
+    const uint32_t cb = valid ? p.chunk_bits[c] : 0u;
+    const uint4 *lut16 = reinterpret_cast<const uint4 *>(p.lut);
+    const uint4 lut0 = threadIdx.x < lut_bytes / 16 ? lut16[threadIdx.x] : make_uint4(0, 0, 0, 0);
+    // (straight-line on purpose: a load behind a branch is waited for at once)
+    const uint64_t last_seg = (p.n_chunks - 1) / HF_SEG_CHUNKS;
+    const uint64_t so0 = p.seg_off[seg], so1 = p.seg_off[min(seg + 1, last_seg)];
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t seg_start = so0 - p.bit_base;
+    const uint64_t ubase = seg_start >> 7;
+    const uint32_t s_lo = (uint32_t)(seg_start & 127u);
+    constexpr uint32_t IMG_CAP = HF_SEG_CHUNKS * CS / 4 + 16; // words
+    constexpr int EARLY = 4;                                  // 16-byte units per lane
+    const uint64_t whole = p.in_bytes >> 4;
+    const uint4 *in16 = reinterpret_cast<const uint4 *>(p.in);
+    uint32_t nunits_e = 0;
+    if (seg < last_seg && p.in_aligned16 && so1 - so0 <= (uint64_t)IMG_CAP * 32u) {
+        nunits_e = (uint32_t)((s_lo + (so1 - so0) + 127u) / 128u) + 1u;
+        if (nunits_e * 4u > IMG_CAP || ubase + nunits_e > whole)
+            nunits_e = 0;
+    }
+    uint4 st[EARLY];
+    {
+        // unconditional: without a span to fetch, the loads re-read the table
+        const uint4 *from = nunits_e ? in16 + ubase : lut16;
+        const uint32_t top = nunits_e ? nunits_e - 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < EARLY; ++k)
+            st[k] = from[min(threadIdx.x + k * DEC_THREADS, top)];
+    }
+    __builtin_amdgcn_sched_barrier(0); // loads return in order: the small ones were issued first
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        if (threadIdx.x < lut_bytes / 16)
+            dst[threadIdx.x] = lut0;
+        for (uint32_t i = threadIdx.x + DEC_THREADS; i < lut_bytes / 16; i += DEC_THREADS)
+            dst[i] = lut16[i];
+    }
+    uint32_t total;
+    const uint32_t excl = block_excl_scan256(cb, s_wave, total);
+    DEC_TRACE(1); // gap array and table in, chunk offsets scanned
+    const uint32_t nunits = (s_lo + total + 127u) / 128u + 1u; // +1: readers run ahead
+    const bool use_lds = nunits * 4u <= IMG_CAP && p.in_aligned16;
+    if (use_lds) {
+        auto put = [&](uint32_t i, uint4 v) {
+            if (SWZ) { // word w of the image lives in slot w + w / 32 (see SwzWords)
+                uint32_t *dst = img + 4 * i + ((4 * i) >> 5);
+                dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+            } else {
+                reinterpret_cast<uint4 *>(img)[i] = v;
+            }
+        };
+        // (a gap array whose chunk lengths exceed the segment's span is
+        // inconsistent: everything is then fetched here, as for the last segment)
+        const bool early_ok = nunits <= nunits_e;
+        if (early_ok) {
+#pragma unroll
+            for (int k = 0; k < EARLY; ++k) {
+                const uint32_t i = threadIdx.x + k * DEC_THREADS;
+                if (i < nunits) {
+                    uint4 v = st[k];
+                    v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
+                    put(i, v);
+                }
+            }
+        }
+        for (uint32_t i = threadIdx.x + (early_ok ? EARLY * DEC_THREADS : 0); i < nunits;
+             i += DEC_THREADS) {
+            const uint64_t u = ubase + i;
+            uint4 v;
+            if (u < whole) {
+                v = in16[u];
+                v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
+            } else {
+                v.x = dec_load_word(p.in, p.in_bytes, u * 4 + 0);
+                v.y = dec_load_word(p.in, p.in_bytes, u * 4 + 1);
+                v.z = dec_load_word(p.in, p.in_bytes, u * 4 + 2);
+                v.w = dec_load_word(p.in, p.in_bytes, u * 4 + 3);
+            }
+            put(i, v);
+        }
+    }
+    DEC_TRACE(2); // stream image staged (this wave's share)
+    __syncthreads();
+    DEC_TRACE(3);
+
+    const uint64_t sym0 = c * CS;
+    const uint32_t cnt = valid ? (uint32_t)min((uint64_t)CS, p.n_out - sym0) : 0u;
+    const bool fast = use_lds && cnt == (uint32_t)CS;
+    uint32_t outw[CS / 4];
+    bool bad = false;
+    bool dirty = false; // SPEC: some group of K codes ran past its 64-bit window
+    if (fast && K >= 8 && !ESC && !SPEC) {
+        // codes of at most 8 bits: a streaming reader that merges one word per
+        // 32 consumed bits touches LDS least (one word per four symbols)
+        Img src{img};
+        BitReader<Img> br(src, s_lo + excl);
+        const uint32_t shift = 32 - p.w1;
+#pragma unroll
+        for (int i = 0; i < CS / 4; ++i) {
+            uint32_t pack = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k == 0)
+                    br.refill();
+                pack |= dec_symbol<Img, false>(br, s_lut, shift, p, bad) << (8 * k);
+            }
+            outw[i] = pack;
+        }
+    } else if (fast) {
+        // No reader state besides the bit position: every K symbols the lane
+        // rebuilds a 64-bit window from the three image words at its position;
+        // no refill branches.  Either K * sentinel <= 64, so the window cannot
+        // run dry, or (SPEC, prefix-free models only) the host chose K so that
+        // K codes practically never exceed 64 bits; a lane to which it happens
+        // anyway is marked dirty and decodes its chunk again at the end.
+        uint32_t pos = s_lo + excl;
+        const uint32_t shift = 32 - p.w1;
+#pragma unroll
+        for (int i = 0; i < CS / 4; ++i)
+            outw[i] = 0;
+#pragma unroll
+        for (int g = 0; g < CS; g += K) {
+            const Img src{img};
+            const uint32_t wi = pos >> 5;
+            const uint32_t w0 = src(wi), w1 = src(wi + 1), w2 = src(wi + 2);
+            const uint32_t sh = 32u - (pos & 31u); // 1..32
+            const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
+            const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
+            uint64_t win = ((uint64_t)hi << 32) | lo;
+            uint32_t used = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int j = g + k;
+                if (j < CS) {
+                    uint32_t e = s_lut[(uint32_t)(win >> 32) >> shift];
+                    if (ESC && __builtin_expect((e & 0x8000u) != 0, 0))
+                        e = dec_escape_window(win, e, s_lut, p, bad);
+                    const uint32_t len = e >> 8;
+                    win <<= len;
+                    used += len;
+                    // byte j % 4 of the output word takes the entry's low byte
+                    constexpr uint32_t keep = 0x03020100u;
+                    const uint32_t sel = (keep & ~(0xffu << (8 * (j & 3)))) | (0x04u << (8 * (j & 3)));
+                    outw[j >> 2] = __builtin_amdgcn_perm(e, outw[j >> 2], sel);
+                }
+            }
+            pos += used;
+            if (SPEC)
+                dirty = dirty || used > 64u;
+        }
+    } else if (cnt) {
+        // ragged chunk or oversized segment: bytes go straight to global memory
+        GlobalWords src{p.in, p.in_bytes, ubase * 4};
+        BitReader<GlobalWords> br(src, s_lo + excl);
+        const uint32_t shift = 32 - p.w1;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            br.refill();
+            p.out[sym0 + i] = (uint8_t)dec_symbol<GlobalWords, true>(br, s_lut, shift, p, bad);
+        }
+    }
+    DEC_TRACE(4); // decoded
+    if (bad && !dirty) // a dirty lane's symbols (and errors) are not real: it decodes again below
+        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
+    __syncthreads(); // every lane is done with the compressed image: reuse it for the output
+    if (fast) {
+        uint32_t *orow = img + threadIdx.x * OROW;
+#pragma unroll
+        for (int i = 0; i < CS / 4; ++i)
+            orow[i] = outw[i];
+    }
+    DEC_TRACE(5); // output rows written
+    __syncthreads();
+    DEC_TRACE(6);
+    if (!use_lds)
+        return;
+    // coalesced copy-out of the whole chunks of the segment
+    const uint64_t obase = seg * HF_SEG_CHUNKS * (uint64_t)CS;
+    const uint64_t oleft = p.n_out - obase;
+    const uint32_t full_chunks = (uint32_t)min(oleft / CS, (uint64_t)HF_SEG_CHUNKS);
+    const uint32_t seg_len = full_chunks * CS;
+    for (uint32_t o = threadIdx.x * 16u; o < seg_len; o += DEC_THREADS * 16u) {
+        const uint32_t ch = o / CS, within = o % CS;
+        const uint32_t *srcw = img + ch * OROW + within / 4;
+        uint4 v;
+        v.x = srcw[0];
+        v.y = srcw[1];
+        v.z = srcw[2];
+        v.w = srcw[3];
+        if (p.out_aligned16) {
+            *reinterpret_cast<uint4 *>(p.out + obase + o) = v;
+        } else {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t i = 0; i < 16u; ++i)
+                p.out[obase + o + i] = (uint8_t)(vv[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+    DEC_TRACE(7); // copied out
+    if (SPEC) {
+        __syncthreads(); // the chunk's (wrong) bytes from the image have been stored
+        if (dirty) {
+            GlobalWords src{p.in, p.in_bytes, ubase * 4};
+            BitReader<GlobalWords> br(src, s_lo + excl);
+            const uint32_t shift = 32 - p.w1;
+            bool bad2 = false;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                br.refill();
+                p.out[sym0 + i] = (uint8_t)dec_symbol<GlobalWords, true>(br, s_lut, shift, p, bad2);
+            }
+            if (bad2)
+                atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
+                         (unsigned long long)HF_FLAG_DECODE);
+        }
+    }
+}
+
+// Gap-free decode: one lane walks the whole stream with predecessor search.
+__global__ void dec_serial_kernel(DecParams p)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    uint64_t pos = 0; // may exceed 32 bits: peek relative to the current word
+    bool bad = false;
+    for (uint64_t i = 0; i < p.n_out; ++i) {
+        GlobalWords s2{p.in, p.in_bytes, pos >> 5};
+        const uint64_t window = dec_peek64(s2, (uint32_t)(pos & 31u)) >> (64 - p.sentinel);
+        const int k = dec_predecessor(p.keys, p.m, window);
+        uint32_t len = 0;
+        uint8_t sym = 0;
+        if (k >= 0) {
+            sym = p.ksyms[k];
+            len = p.klens[k];
+        } else {
+            bad = true;
+        }
+        p.out[i] = sym;
+        pos += len;
+    }
+    if (bad)
+        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
+}
+
+} // namespace
+
+#endif // HFGPU_KERN_DECODE_HPP
