@@ -508,8 +508,27 @@ def test_full_size_round_trip_properties(dev, kind, gib):
     out = dev.decode(enc, model)
     assert torch.equal(out, data)
     del out
+    # ... the planned encoder (batch histograms of the counting pass) included;
+    # at 4 GiB its start bits exceed 32 bits
     again = dev.encode(data, model)
     assert torch.equal(again.stream(), enc.stream())
+    del again
+    bh = dev.new_batch_hist(n, data.device)
+    d_hist = dev.histogram_async(data, batch_hist=bh)
+    assert np.array_equal(d_hist.cpu().numpy().astype(np.uint64), hist)
+    assert int(bh[: (n >> 16) * 256].sum(dtype=torch.int64)) == n
+    enc.data[: enc.nbytes].zero_()  # same buffers, so that 4 GiB cases fit: clear, re-encode, decode
+    bufs = dev.EncodeBuffers.__new__(dev.EncodeBuffers)
+    bufs.n, bufs.chunk_syms, bufs.cap = n, 64, enc.data.numel()
+    bufs.data, bufs.chunk_bits, bufs.seg_off = enc.data, enc.chunk_bits, enc.seg_off
+    bufs.result = torch.zeros(4, dtype=torch.int64, device=data.device)
+    keep_cb = enc.chunk_bits.clone()
+    dev.encode_async(data, model, bufs, plan=bh)
+    torch.cuda.synchronize()
+    assert bufs.result.tolist()[:2] == [enc.total_bits, 0]
+    assert torch.equal(keep_cb, enc.chunk_bits)
+    out = dev.decode(enc, model)
+    assert torch.equal(out, data)
 
 
 # ------------------------------------------------------------ random models
