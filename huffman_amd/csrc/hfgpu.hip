@@ -554,6 +554,8 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
     mod->enc_spec = speculative;
     rc = upload_model(ctx, mod, enc, enc2, lut, keys, syms, klens, m);
     if (rc != HF_OK) {
+        if (mod->d_blob) // taken from the cache or allocated before the failing step
+            (void)hipFree(mod->d_blob);
         delete mod;
         return rc;
     }
@@ -594,6 +596,8 @@ int hf_model_from_table(hf_ctx *ctx, const uint64_t *keys, const uint8_t *syms,
     mod->has_encode = false;
     rc = upload_model(ctx, mod, nullptr, nullptr, lut, keys, syms, klens, m);
     if (rc != HF_OK) {
+        if (mod->d_blob) // taken from the cache or allocated before the failing step
+            (void)hipFree(mod->d_blob);
         delete mod;
         return rc;
     }
