@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-plan", action="store_true",
                     help="encode without the batch histograms of the counting pass "
                          "(single-pass chained scan instead)")
+    ap.add_argument("--hist-grid", type=int, default=0,
+                    help="workgroups of the counting pass (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--seed", type=int, default=2024)
@@ -106,6 +108,7 @@ def main():
     data = synth.generate_device(args.kind, n, seed=args.seed + rank, device=dev)
     ctx = hd.Context.get(dev)
     ctx.set_option("enc_mode", args.enc_mode)
+    ctx.set_option("hist_grid", args.hist_grid)
     cs = args.chunk_syms
 
     d_hist = torch.empty(256, dtype=torch.int64, device=dev)
