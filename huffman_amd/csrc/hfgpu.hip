@@ -63,6 +63,10 @@ struct hf_ctx {
     unsigned pinned_next = 0;
     void *arena = nullptr; // device staging of the *_host entry points (grow only)
     size_t arena_bytes = 0;
+    // hf_decode_host moves large buffers in pieces: upload, decode and download
+    // of consecutive pieces overlap on three streams
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    int host_piece_mib = 64;
     // option "kernel_timing": HIP events around the dominant kernel of every
     // histogram / encode / decode call (on the stream it is launched on), kept
     // in a ring until hf_ctx_kernel_ms collects them
@@ -360,6 +364,10 @@ int hf_ctx_destroy(hf_ctx *ctx)
         (void)hipFree(ctx->arena);
     for (auto &b : ctx->blob_cache)
         (void)hipFree(b.d);
+    if (ctx->up_stream)
+        (void)hipStreamDestroy(ctx->up_stream);
+    if (ctx->down_stream)
+        (void)hipStreamDestroy(ctx->down_stream);
     for (auto &t : ctx->timed)
         for (auto &ev : t.ring) {
             (void)hipEventDestroy(ev.first);
@@ -423,6 +431,8 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
         ctx->hist_grid = (int)value;
     else if (!std::strcmp(name, "timeout_ms") && value > 0 && value <= 60000)
         ctx->timeout_ms = (int)value;
+    else if (!std::strcmp(name, "host_piece_mib") && value >= 1 && value <= 4096)
+        ctx->host_piece_mib = (int)value;
     else if (!std::strcmp(name, "kernel_timing"))
         ctx->kernel_timing = value != 0;
     else if (!std::strcmp(name, "dec_trace")) // device address, 128 bytes per segment; 0 = off
@@ -1120,6 +1130,207 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
 
 // ------------------------------------------------------- host-buffer forms
 
+} // extern "C"
+
+namespace {
+
+// hf_encode_host for an input of several pieces: all uploads are queued on the
+// upload stream at once; every piece is encoded as a stream of its own that
+// starts with the bits the previous pieces left in their last byte
+// (lead_bits), so the pieces concatenate bytewise and only the byte two pieces
+// share is OR-merged on the host.  A piece's length is needed before the next
+// can start; that wait only idles the (barely loaded) compute stream, uploads
+// and downloads keep running.  Two output buffers take turns.
+int encode_host_pieces(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint64_t n,
+                       uint32_t lead_bits, uint8_t *h_out, uint64_t out_cap, uint32_t chunk_syms,
+                       uint16_t *h_chunk_bits, uint64_t *h_seg_off, uint64_t *total_bits,
+                       uint64_t piece)
+{
+    if (!ctx->up_stream)
+        HF_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+    if (!ctx->down_stream)
+        HF_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+    const uint64_t pieces = (n + piece - 1) / piece;
+    uint64_t n_chunks = 0, n_segs = 0;
+    if (h_chunk_bits)
+        hf_gap_layout(n, chunk_syms, &n_chunks, &n_segs);
+    const uint64_t seg_syms = (uint64_t)HF_SEG_CHUNKS * chunk_syms;
+    const uint64_t cap_piece = align_up(hf_encode_bound(model, piece, 7) + 16, 256);
+    // arena: input | two stream buffers | chunk_bits | seg_off | result blocks
+    const size_t off_out = align_up(n + 16, 256);
+    const size_t off_cb = off_out + 2 * cap_piece;
+    const size_t off_so = align_up(off_cb + n_chunks * 2 + 16, 256);
+    const size_t off_res = align_up(off_so + n_segs * 8 + 16, 256);
+    int rc = ensure_arena(ctx, off_res + pieces * HF_RES_WORDS * sizeof(uint64_t) + 16);
+    if (rc != HF_OK)
+        return rc;
+    uint8_t *a = static_cast<uint8_t *>(ctx->arena);
+    uint16_t *d_cb = reinterpret_cast<uint16_t *>(a + off_cb);
+    uint64_t *d_so = reinterpret_cast<uint64_t *>(a + off_so);
+    uint64_t *d_res = reinterpret_cast<uint64_t *>(a + off_res);
+    std::vector<hipEvent_t> ev(2 * pieces, nullptr); // [2i] uploaded, [2i + 1] downloaded
+    std::vector<uint8_t> first(pieces, 0);           // a piece's first byte when it is shared ...
+    std::vector<uint8_t> shared(pieces, 0);          // ... with the last byte of its predecessor
+    std::vector<uint64_t> base(pieces, 0);           // stream bit at which a piece's own bits start
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == HF_OK)
+            rc = fail(ctx, HF_ERR_HIP, "hf_encode_host: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (auto &e : ev)
+        if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event"))
+            break;
+    for (uint64_t i = 0; i < pieces && rc == HF_OK; ++i) {
+        const uint64_t at = i * piece, len = std::min(piece, n - at);
+        hip_ok(hipMemcpyAsync(a + at, h_in + at, len, hipMemcpyHostToDevice, ctx->up_stream),
+               "upload");
+        hip_ok(hipEventRecord(ev[2 * i], ctx->up_stream), "record");
+    }
+    uint64_t running = lead_bits; // bits of the stream so far, the caller's lead bits included
+    for (uint64_t i = 0; i < pieces && rc == HF_OK; ++i) {
+        const uint64_t at = i * piece, len = std::min(piece, n - at);
+        const uint32_t lead = (uint32_t)(running & 7u);
+        uint8_t *d_out = a + off_out + (i & 1) * cap_piece;
+        hip_ok(hipStreamWaitEvent(ctx->stream, ev[2 * i], 0), "wait");
+        if (i >= 2) // the buffer is free once the piece before the last has been downloaded
+            hip_ok(hipStreamWaitEvent(ctx->stream, ev[2 * (i - 2) + 1], 0), "wait");
+        if (rc != HF_OK)
+            break;
+        uint64_t *res_i = d_res + i * HF_RES_WORDS;
+        rc = hf_encode_async(ctx, model, a + at, len, lead, d_out, cap_piece, chunk_syms,
+                             h_chunk_bits ? d_cb + at / chunk_syms : nullptr,
+                             h_seg_off ? d_so + at / seg_syms : nullptr, res_i);
+        if (rc != HF_OK)
+            break;
+        uint64_t res[HF_RES_WORDS] = {0};
+        if (!hip_ok(hipMemcpyAsync(res, res_i, sizeof(res), hipMemcpyDeviceToHost, ctx->stream),
+                    "result") ||
+            !hip_ok(hipStreamSynchronize(ctx->stream), "synchronize"))
+            break;
+        if ((rc = flags_to_status(ctx, res[HF_RES_FLAGS])) != HF_OK)
+            break;
+        const uint64_t bits = res[HF_RES_TOTAL_BITS];
+        const uint64_t nbytes = (lead + bits + 7) / 8, dst = running / 8;
+        if (dst + nbytes > out_cap) {
+            rc = fail(ctx, HF_ERR_CAPACITY, "hf_encode_host: output buffer too small");
+            break;
+        }
+        // the byte shared with the previous piece is merged after all downloads
+        const uint64_t skip = (lead != 0 && i > 0 && nbytes > 0) ? 1 : 0;
+        shared[i] = (uint8_t)skip;
+        if (skip)
+            hip_ok(hipMemcpyAsync(&first[i], d_out, 1, hipMemcpyDeviceToHost, ctx->down_stream),
+                   "download");
+        if (nbytes > skip)
+            hip_ok(hipMemcpyAsync(h_out + dst + skip, d_out + skip, nbytes - skip,
+                                  hipMemcpyDeviceToHost, ctx->down_stream), "download");
+        hip_ok(hipEventRecord(ev[2 * i + 1], ctx->down_stream), "record");
+        base[i] = running - lead;
+        running += bits;
+    }
+    if (rc == HF_OK && h_chunk_bits && n_chunks) {
+        hip_ok(hipMemcpyAsync(h_chunk_bits, d_cb, n_chunks * 2, hipMemcpyDeviceToHost,
+                              ctx->down_stream), "download");
+        hip_ok(hipMemcpyAsync(h_seg_off, d_so, n_segs * 8, hipMemcpyDeviceToHost, ctx->down_stream),
+               "download");
+    }
+    (void)hipStreamSynchronize(ctx->up_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    hip_ok(hipStreamSynchronize(ctx->down_stream), "synchronize");
+    for (auto &e : ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (rc != HF_OK)
+        return rc;
+    for (uint64_t i = 0; i < pieces; ++i)
+        if (shared[i]) // base[i] / 8 is the byte the piece shares with its predecessor
+            h_out[base[i] / 8] |= first[i];
+    if (h_seg_off) { // a piece counted its segment offsets from its own first byte
+        const uint64_t segs_per_piece = piece / seg_syms;
+        for (uint64_t sgm = 0; sgm < n_segs; ++sgm)
+            h_seg_off[sgm] += base[sgm / segs_per_piece];
+    }
+    if (total_bits)
+        *total_bits = running - lead_bits;
+    return HF_OK;
+}
+
+// hf_decode_host for a stream with gap arrays that spans several pieces of
+// `piece_segs` segments: the gap arrays are on the device already (queued on the
+// context's stream); piece i needs the stream bytes up to the start of piece
+// i + 1 (plus what the readers run ahead), which the upload stream delivers in
+// order; the decode of piece i waits for its upload, the download stream for
+// its decode.  Every piece has its own result block; their flags are merged.
+int decode_host_pieces(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint64_t in_bytes,
+                       uint64_t n_out, uint32_t chunk_syms, const uint64_t *h_seg_off,
+                       const uint16_t *d_cb, const uint64_t *d_so, uint8_t *d_in, uint8_t *d_out,
+                       uint8_t *h_out, uint64_t piece_segs, uint64_t pieces, uint64_t *d_res)
+{
+    if (!ctx->up_stream)
+        HF_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+    if (!ctx->down_stream)
+        HF_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+    const uint64_t seg_syms = (uint64_t)HF_SEG_CHUNKS * chunk_syms;
+    const uint64_t n_segs = (n_out + seg_syms - 1) / seg_syms;
+    std::vector<hipEvent_t> ev(2 * pieces, nullptr);
+    int rc = HF_OK;
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == HF_OK)
+            rc = fail(ctx, HF_ERR_HIP, "hf_decode_host: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    for (auto &e : ev)
+        if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event"))
+            break;
+    uint64_t uploaded = 0;
+    for (uint64_t i = 0; i < pieces && rc == HF_OK; ++i) {
+        const uint64_t s0 = i * piece_segs, s1 = std::min(n_segs, s0 + piece_segs);
+        // bytes this piece may touch: up to the next piece's first bit, plus run-ahead
+        uint64_t need = s1 < n_segs ? std::min<uint64_t>(in_bytes, (h_seg_off[s1] / 8 + 64 + 15) & ~15ull)
+                                    : in_bytes;
+        need = std::max(need, uploaded);
+        if (need > uploaded)
+            hip_ok(hipMemcpyAsync(d_in + uploaded, h_in + uploaded, need - uploaded,
+                                  hipMemcpyHostToDevice, ctx->up_stream), "upload");
+        uploaded = need;
+        hip_ok(hipEventRecord(ev[2 * i], ctx->up_stream), "record");
+        hip_ok(hipStreamWaitEvent(ctx->stream, ev[2 * i], 0), "wait");
+        if (rc != HF_OK)
+            break;
+        const uint64_t sym0 = s0 * seg_syms;
+        const uint64_t n_piece = std::min(n_out, s1 * seg_syms) - sym0;
+        rc = hf_decode_async(ctx, model, d_in, in_bytes, 0, n_piece, chunk_syms,
+                             d_cb + s0 * HF_SEG_CHUNKS, d_so + s0, d_out + sym0,
+                             d_res + i * HF_RES_WORDS);
+        if (rc != HF_OK)
+            break;
+        hip_ok(hipEventRecord(ev[2 * i + 1], ctx->stream), "record");
+        hip_ok(hipStreamWaitEvent(ctx->down_stream, ev[2 * i + 1], 0), "wait");
+        hip_ok(hipMemcpyAsync(h_out + sym0, d_out + sym0, n_piece, hipMemcpyDeviceToHost,
+                              ctx->down_stream), "download");
+    }
+    std::vector<uint64_t> res(pieces * HF_RES_WORDS, 0);
+    (void)hipStreamSynchronize(ctx->up_stream);
+    hip_ok(hipStreamSynchronize(ctx->stream), "synchronize");
+    hip_ok(hipStreamSynchronize(ctx->down_stream), "synchronize");
+    if (rc == HF_OK)
+        hip_ok(hipMemcpy(res.data(), d_res, res.size() * sizeof(uint64_t), hipMemcpyDeviceToHost),
+               "results");
+    for (auto &e : ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (rc != HF_OK)
+        return rc;
+    uint64_t flags = 0;
+    for (uint64_t i = 0; i < pieces; ++i)
+        flags |= res[i * HF_RES_WORDS + HF_RES_FLAGS];
+    return flags_to_status(ctx, flags);
+}
+
+} // namespace
+
+extern "C" {
+
 int hf_histogram_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n, uint64_t hist[256])
 {
     if (!ctx || !hist || (!h_in && n))
@@ -1143,6 +1354,12 @@ int hf_encode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
     uint64_t n_chunks = 0, n_segs = 0;
     if (h_chunk_bits && hf_gap_layout(n, chunk_syms, &n_chunks, &n_segs) != HF_OK)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_host: chunk_syms must be 64, 128 or 256");
+    if (lead_bits > 7)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_host: lead_bits must be 0..7");
+    const uint64_t piece = (uint64_t)ctx->host_piece_mib << 20; // a multiple of every segment size
+    if (n > piece)
+        return encode_host_pieces(ctx, model, h_in, n, lead_bits, h_out, out_cap, chunk_syms,
+                                  h_chunk_bits, h_seg_off, total_bits, piece);
     // arena layout: input | stream | chunk_bits | seg_off, each 256-byte aligned
     const uint64_t bound = std::min<uint64_t>(hf_encode_bound(model, n, lead_bits),
                                               (out_cap + 3) & ~3ull);
@@ -1284,12 +1501,19 @@ int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
     const size_t off_out = align_up(in_bytes + 16, 256);
     const size_t off_cb = align_up(off_out + n_out + 16, 256);
     const size_t off_so = align_up(off_cb + n_chunks * 2 + 16, 256);
-    const size_t total = off_so + n_segs * 8 + 16;
+    // with side metadata at hand, a large stream goes through the device in pieces
+    // of whole segments whose upload, decode and download overlap
+    const uint64_t seg_syms = (uint64_t)HF_SEG_CHUNKS * chunk_syms;
+    const uint64_t piece_segs =
+        std::max<uint64_t>(1, ((uint64_t)ctx->host_piece_mib << 20) / std::max<uint64_t>(seg_syms, 1));
+    const uint64_t pieces = (!rebuild && n_segs > piece_segs) ? (n_segs + piece_segs - 1) / piece_segs : 1;
+    const size_t off_res = align_up(off_so + n_segs * 8 + 16, 256);
+    const size_t total = off_res + pieces * HF_RES_WORDS * sizeof(uint64_t) + 16;
     int rc = ensure_arena(ctx, total);
     if (rc != HF_OK)
         return rc;
     uint8_t *a = static_cast<uint8_t *>(ctx->arena);
-    if (in_bytes)
+    if (in_bytes && pieces == 1)
         HF_HIP(ctx, hipMemcpyAsync(a, h_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     uint16_t *d_cb = reinterpret_cast<uint16_t *>(a + off_cb);
     uint64_t *d_so = reinterpret_cast<uint64_t *>(a + off_so);
@@ -1311,6 +1535,10 @@ int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
     }
     if (serial)
         rc = hf_decode_serial(ctx, model, a, in_bytes, 0, n_out, a + off_out);
+    else if (pieces > 1)
+        return decode_host_pieces(ctx, model, h_in, in_bytes, n_out, chunk_syms, h_seg_off, d_cb,
+                                  d_so, a, a + off_out, h_out, piece_segs, pieces,
+                                  reinterpret_cast<uint64_t *>(a + off_res));
     else if (n_out)
         rc = hf_decode(ctx, model, a, in_bytes, 0, n_out, chunk_syms, d_cb, d_so, a + off_out);
     if (rc != HF_OK)

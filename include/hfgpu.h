@@ -81,6 +81,9 @@ HF_API const char *hf_last_error(const hf_ctx *ctx);
 /* Knobs: "enc_mode" (1 = single pass with a chained scan between workgroups,
  * the default; 0 = three kernels, no waiting between workgroups),
  * "hist_grid" (workgroups of the histogram kernel, 0 = four per CU),
+ * "host_piece_mib" (hf_encode_host and hf_decode_host move larger buffers
+ * through the device in pieces of this many MiB, default 64, so that upload,
+ * compute and download overlap),
  * "timeout_ms" (bound on the waits of the chained scan; when it expires the
  * call returns HF_ERR_INTERNAL), "debug" (bit mask that skips phases of the
  * encoder for timing experiments -- results are then wrong on purpose). */
@@ -261,8 +264,12 @@ HF_API int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t 
  * `&[u8]` / `Vec<u8>` binding passes): the library stages the buffers through
  * a device arena owned by the context (grow only, reused between calls),
  * copies over PCIe, runs the device entry point on the context's stream and
- * synchronises.  Gap arrays are optional; without them hf_decode_host falls
- * back to the sequential device walk. */
+ * synchronises.  hf_encode_host, and hf_decode_host when it is given gap arrays,
+ * move buffers above "host_piece_mib" in pieces whose upload, encode / decode
+ * and download overlap (results are those of a single call).  Gap arrays are
+ * optional; without them hf_decode_host rebuilds them on the device
+ * (hf_build_gap_array) and walks sequentially only through streams that end
+ * early. */
 HF_API int hf_histogram_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n, uint64_t hist[256]);
 HF_API int hf_encode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint64_t n,
                           uint32_t lead_bits, uint8_t *h_out, uint64_t out_cap,
