@@ -173,3 +173,22 @@ def test_gap_layout_and_bad_chunk_size():
     assert lib().hf_gap_layout(1, 64, C.byref(nc), C.byref(ns)) == 0
     assert nc.value == 1 and ns.value == 1
     assert lib().hf_gap_layout(100, 100, C.byref(nc), C.byref(ns)) == _lib.HF_ERR_BAD_ARG
+
+
+def test_batch_histogram_size_and_null_context_calls():
+    """Host-only parts of the planned-encode and timing entry points."""
+    import ctypes as C
+
+    from huffman_amd import _lib
+
+    L = _lib.lib()
+    assert L.hf_batch_hist_bytes(0) == 0
+    assert L.hf_batch_hist_bytes(1) == 1024
+    assert L.hf_batch_hist_bytes(_lib.HF_PLAN_BATCH) == 1024
+    assert L.hf_batch_hist_bytes(_lib.HF_PLAN_BATCH + 1) == 2048
+    assert L.hf_batch_hist_bytes(1 << 30) == (1 << 30) // 64
+    ms, cnt = C.c_double(), C.c_uint64()
+    assert L.hf_ctx_kernel_ms(None, 0, C.byref(ms), C.byref(cnt)) == _lib.HF_ERR_BAD_ARG
+    assert L.hf_histogram_batches_async(None, None, 0, None, None) == _lib.HF_ERR_BAD_ARG
+    assert L.hf_encode_planned_async(None, None, None, 0, 0, None, None, 0, 64, None, None,
+                                     None) == _lib.HF_ERR_BAD_ARG
