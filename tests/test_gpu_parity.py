@@ -708,3 +708,72 @@ def test_planned_encode_detects_histograms_of_other_data(dev, orc):
     dev.encode_async(to_gpu(a), model, bufs, plan=bh)  # ... used for a
     torch.cuda.synchronize()
     assert int(bufs.result[1].item()) & 8  # HF_FLAG_PLAN
+
+
+@pytest.mark.parametrize("kind,cs", [("zipf", 64), ("geometric", 64), ("uniform", 128), ("testfile", 256)])
+def test_decode_a_byte_range_of_the_stream_with_bit_base(dev, orc, kind, cs):
+    """Multi-GPU decode of one stream: a rank holds only the bytes of its range of
+    segments (copied to a buffer of its own), the gap-array slices keep their
+    absolute bit offsets, and bit_base tells where the buffer starts."""
+    import torch
+
+    n = 3_000_017
+    data = synth.generate_host(kind, n, seed=cs + 1)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model, chunk_syms=cs)
+    seg_syms = 256 * cs
+    n_segs = (n + seg_syms - 1) // seg_syms
+    so = enc.seg_off.cpu().numpy().view(np.uint64)
+    stream = enc.stream()
+    world = 3
+    bounds = [n_segs * r // world for r in range(world + 1)]
+    for r in range(world):
+        s0, s1 = bounds[r], bounds[r + 1]
+        if s1 == s0:
+            continue
+        first = (int(so[s0]) // 8) & ~3                       # 4-byte aligned start of the range
+        last = enc.nbytes if s1 == n_segs else min(enc.nbytes, int(so[s1]) // 8 + 1)
+        mine = stream[first:last].clone()                      # what this rank holds
+        sym0, sym1 = s0 * seg_syms, min(n, s1 * seg_syms)
+        out = torch.empty(sym1 - sym0, dtype=torch.uint8, device=mine.device)
+        res = torch.zeros(4, dtype=torch.int64, device=mine.device)
+        dev.decode_async(mine, last - first, model, sym1 - sym0, cs,
+                         enc.chunk_bits[s0 * 256:], enc.seg_off[s0:], out, res, bit_base=8 * first)
+        torch.cuda.synchronize()
+        assert res.tolist()[1] == 0
+        assert np.array_equal(out.cpu().numpy(), data[sym0:sym1]), f"rank {r}"
+
+
+@pytest.mark.parametrize("kind", ["zipf", "geometric"])
+def test_shards_with_lead_bits_concatenate_to_the_whole_stream(dev, orc, kind):
+    """Multi-GPU encode in one process: per-shard batch histograms give the plan
+    (as bench.py derives it from one all-gather), every shard is encoded with the
+    planned encoder and its lead bits, and the shards OR-merged at their byte
+    ranges are the stream of the whole input."""
+    import torch
+
+    from huffman_amd.dist import plan_from_histograms
+
+    world = 3
+    n_each = [700_001, 65536 * 5, 412_345]
+    parts = [synth.generate_host(kind, m, seed=40 + r) for r, m in enumerate(n_each)]
+    whole = np.concatenate(parts)
+    hists = np.stack([orc.histogram(p) for p in parts])
+    codes, lens = orc.generate_extended_codewords(hists.sum(axis=0).astype(np.uint64))
+    want, _ = orc.encode_slice(whole, codes, lens)
+    model = dev.DeviceModel(codes, lens)
+    merged = np.zeros(want.size, dtype=np.uint8)
+    for r in range(world):
+        plan = plan_from_histograms(hists, lens, r)
+        t = to_gpu(parts[r])
+        bh = dev.new_batch_hist(t.numel(), t.device)
+        dev.histogram_async(t, batch_hist=bh)
+        bufs = dev.EncodeBuffers(model, t.numel(), 64, lead_bits=plan.lead_bits)
+        dev.encode_async(t, model, bufs, lead_bits=plan.lead_bits, plan=bh)
+        torch.cuda.synchronize()
+        assert bufs.result.tolist()[:2] == [plan.bits[r], 0]
+        first, last = plan.byte_range(r)
+        merged[first:last] |= bufs.data[: last - first].cpu().numpy()
+    assert plan.total_bytes == want.size
+    assert np.array_equal(merged, want)
