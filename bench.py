@@ -2,50 +2,60 @@
 """Throughput of the Huffman hot path on MI355X.
 
 One step = one full pass of the path over a synthetic byte stream that is
-already resident in HBM:  histogram -> host codebook -> device tables ->
-encode (+ gap array) -> decode.  `value` is uncompressed GB/s of that round
-trip (bytes of all ranks / max-over-ranks time); encode-only and decode-only
-rates and per-kernel durations (HIP events on the launch stream, inside the
-timed region) are reported alongside.
+already resident in HBM:  counting pass (histogram + batch histograms) -> host
+codebook -> device tables -> encode (+ gap array) -> decode.  `value` is
+uncompressed GB/s of that round trip (bytes of all ranks / max-over-ranks
+time); encode-only and decode-only rates and per-kernel durations (HIP events
+on the launch stream, inside the timed region) are reported alongside.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-N=1: 1 GiB Zipf(s=1.1) stream.  N>1 (launched by torch.distributed.run, one
-rank per GPU): every rank owns a contiguous 1 GiB shard of one logical stream
-(weak scaling; --gib 2 at N=8 is the 16 GiB configuration); the 256-bin
-histograms are all-gathered over RCCL, every rank sums them and builds the same
-codebook, and the exclusive scan of the shards' bit lengths (histogram row x
-code lengths) places each shard at its own bit phase of the global stream.
-The compressed shards stay where they are unless --gather.
+
+N = 1: the headline workload is the 1 GiB Zipf(s=1.1) stream.  Unless a single
+workload is asked for with --kind / --gib, the same process then measures the
+other single-GPU configurations -- 1 GiB uniform, 4 GiB geometric(p=0.5) and
+the 16 GiB Zipf stream that the multi-GPU runs split -- and reports them in
+the "configs" array of the same JSON line.
+
+N > 1: ONE logical 16 GiB Zipf stream (--total-gib) is cut into N contiguous
+shards of 16/N GiB, one rank per GPU (strong scaling).  The 256-bin histograms
+are all-gathered over RCCL, every rank sums them and builds the same codebook,
+and the exclusive scan of the shards' bit lengths (histogram row x code
+lengths) places each shard at its own bit phase of the global stream.  The
+compressed shards stay where they are unless --gather.  The ranks are either
+started by `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE
+in the environment) or, when bench.py is run plainly with --gpus N, by
+bench.py itself: it starts that same launcher as a child process before it
+touches a GPU and passes the child's JSON line through.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from huffman_amd import device as hd  # noqa: E402
-from huffman_amd import synth  # noqa: E402
-from huffman_amd.dist import gather_histograms, plan_from_histograms  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+GIB = 1 << 30
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform", "geometric", "testfile"])
-    ap.add_argument("--gib", type=float, default=None, help="GiB per GPU (default 1)")
-    ap.add_argument("--chunk-syms", type=int, default=hd.DEFAULT_CHUNK_SYMS)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 100 at N=1, 20 for the 16 GiB stream at N>1)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--kind", default=None, choices=["zipf", "uniform", "geometric", "testfile"])
+    ap.add_argument("--gib", type=float, default=None,
+                    help="GiB per GPU; with --kind or --gib only this one workload is run")
+    ap.add_argument("--total-gib", type=float, default=16.0,
+                    help="N>1: size of the one logical stream the ranks share")
+    ap.add_argument("--chunk-syms", type=int, default=64)
     ap.add_argument("--enc-mode", type=int, default=1)
     ap.add_argument("--gather", action="store_true", help="also gather the shards to rank 0")
     ap.add_argument("--no-plan", action="store_true",
@@ -54,20 +64,40 @@ def parse():
     ap.add_argument("--hist-grid", type=int, default=0,
                     help="workgroups of the counting pass (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N=1: skip the uniform / geometric / 16 GiB sub-records")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--seed", type=int, default=2024)
     return ap.parse_args()
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a
+    child job (torch.distributed.run, one process per GPU) and hand its result
+    line through.  Nothing in this process has touched a GPU: torch is not even
+    imported yet."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 class Stage:
     """Accumulates HIP-event durations of one kernel group."""
 
-    def __init__(self):
+    def __init__(self, torch):
+        self.torch = torch
         self.pairs = []
 
     def start(self):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        e0 = self.torch.cuda.Event(enable_timing=True)
+        e1 = self.torch.cuda.Event(enable_timing=True)
         e0.record()
         self.pairs.append((e0, e1))
 
@@ -78,34 +108,31 @@ class Stage:
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(1, len(self.pairs))
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    # HF_BENCH_FORCE_DIST=1 runs the collectives with a single rank too (a
-    # rehearsal of the multi-GPU code path on a one-GPU box)
-    use_dist = world > 1 or os.environ.get("HF_BENCH_FORCE_DIST") == "1"
-    json_fd = None
-    if use_dist:
-        import torch.distributed as dist  # noqa: F811
+def tie_count(hist) -> int:
+    """Symbols whose count equals another symbol's: the reference's sort leaves
+    their order (and so their codes, not their lengths) to the toolchain
+    (src/huffman/mod.rs:138, :222-229); here equal counts keep symbol order."""
+    import numpy as np
 
-        # RCCL prints a version banner on stdout when its first communicator
-        # comes up: everything but the result line goes to stderr instead
-        sys.stdout.flush()
-        json_fd = os.dup(1)
-        os.dup2(2, 1)
-        dist.init_process_group("nccl", device_id=dev)
+    nz = np.asarray(hist)[np.asarray(hist) > 0]
+    _, counts = np.unique(nz, return_counts=True)
+    return int(counts[counts > 1].sum())
 
-    gib = args.gib if args.gib is not None else 1.0
-    n = int(gib * (1 << 30))
-    data = synth.generate_device(args.kind, n, seed=args.seed + rank, device=dev)
+
+def run_workload(args, env, kind: str, n: int, steps: int, warmup: int) -> dict:
+    """Times `steps` round trips of one workload (n bytes on this rank) and checks
+    what was timed: result flags clear, stream length = sum(hist x len), decoded
+    bytes equal the input."""
+    import numpy as np
+    import torch
+
+    from huffman_amd import device as hd
+    from huffman_amd import synth
+    from huffman_amd.dist import gather_histograms, plan_from_histograms
+
+    dev, dist, rank, world = env["dev"], env["dist"], env["rank"], env["world"]
+    use_dist = dist is not None
+    data = synth.generate_device(kind, n, seed=args.seed + rank, device=dev)
     ctx = hd.Context.get(dev)
     ctx.set_option("enc_mode", args.enc_mode)
     ctx.set_option("hist_grid", args.hist_grid)
@@ -117,13 +144,12 @@ def main():
     batch_hist = None if args.no_plan else hd.new_batch_hist(n, dev)
     out = torch.empty(n, dtype=torch.uint8, device=dev)
     dres = torch.zeros(4, dtype=torch.int64, device=dev)
-    st_hist, st_enc, st_dec = Stage(), Stage(), Stage()
+    st_hist, st_enc, st_dec = Stage(torch), Stage(torch), Stage(torch)
     bufs = None
     state = {}
 
     def step(timed: bool):
         nonlocal bufs
-        # pass 1: histogram
         if timed:
             st_hist.start()
         hd.histogram_async(data, d_hist, batch_hist=batch_hist)
@@ -146,9 +172,9 @@ def main():
             my_bits = plan.bits[rank]
             lead = plan.lead_bits
         if bufs is None:
-            cap = hd.DeviceModel.encode_bound(model, n, 7)
+            # a Huffman code never needs more than 8 bits per symbol on average
+            cap = (n + 8 + 15) & ~15
             bufs = hd.EncodeBuffers(model, n, cs, out_cap=cap)
-        # pass 2: encode
         if timed:
             st_enc.start()
         hd.encode_async(data, model, bufs, lead_bits=lead, plan=batch_hist)
@@ -159,13 +185,13 @@ def main():
         nbytes = (lead + total_bits + 7) // 8
         if args.gather and use_dist:
             plan.gather(bufs.data[:nbytes], dist)
-        # decode from the gap array
         if timed:
             st_dec.start()
         hd.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
         if timed:
             st_dec.stop()
-        state.update(model=model, nbytes=nbytes, total_bits=total_bits, lens=lens, hist=hist)
+        state.update(model=model, nbytes=nbytes, total_bits=total_bits, lens=lens, hist=hist,
+                     plan=plan)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -174,13 +200,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     ctx.set_option("kernel_timing", 1)  # HIP events around the three dominant kernels
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(False)
     sync_all()
     for kind_id in range(3):
         ctx.kernel_ms(kind_id)  # drop the warm-up launches
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(True)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -197,9 +223,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = bool(t.item())
 
-    ms_step = elapsed / args.steps * 1e3
-    total_bytes = n * world
-    value = total_bytes / (elapsed / args.steps) / 1e9
+    ms_step = elapsed / steps * 1e3
     C = state["nbytes"]
     # per stage: HIP events around the whole call (helper kernels and launch gaps
     # included); per kernel: the library's events around the dominant kernel alone,
@@ -211,94 +235,80 @@ def main():
         total, launches = ctx.kernel_ms(kind_id)
         kern_ms[name] = total / launches if launches else stage_ms[name]
     ctx.set_option("kernel_timing", 0)
-    hist_ms, enc_ms, dec_ms = kern_ms["histogram"], kern_ms["encode"], kern_ms["decode"]
     kernels = {
-        "histogram": {"ms": hist_ms, "alg_bytes": n},
-        "encode": {"ms": enc_ms, "alg_bytes": n + C},
-        "decode": {"ms": dec_ms, "alg_bytes": C + n},
+        "histogram": {"ms": kern_ms["histogram"], "alg_bytes": n},
+        "encode": {"ms": kern_ms["encode"], "alg_bytes": n + C},
+        "decode": {"ms": kern_ms["decode"], "alg_bytes": C + n},
     }
     for k in kernels.values():
         k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
-    dom = max(("encode", "decode"), key=lambda k: kernels[k]["ms"])
+    # the kernel that runs furthest below the roofline
+    dom = min(("encode", "decode"), key=lambda k: kernels[k]["GBps"])
+    maxlen = int(state["lens"].max())
+    traffic, traffic_source = pmc_traffic(kind, n, cs, dom)
     roofline = {
         "bound": "hbm",
         "kernel": {"encode": "enc_pack_kernel",
                    # (larger chunks of a model whose table needs a second level take dec_kernel)
-                   "decode": "dec_kernel_reg" if cs == 64 or int(state["lens"].max()) <= 11
-                   else "dec_kernel"}[dom],
+                   "decode": "dec_kernel_reg" if cs == 64 or maxlen <= 11 else "dec_kernel"}[dom],
         "achieved": round(kernels[dom]["GBps"], 1),
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBPS, 4),
-        "traffic": pmc_traffic(args.kind, n, cs, dom),
+        "traffic": traffic,
+        "traffic_source": traffic_source,
         "alg_bytes": kernels[dom]["alg_bytes"],
     }
-
-    result = {
-        "metric": "encode+decode GB/s (uncompressed)",
-        "value": round(value, 2),
-        "unit": "GB/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
+    rec = {
+        "workload": f"{n / GIB:g} GiB {kind} per GPU x {world} GPU",
+        "kind": kind,
+        "bytes_per_gpu": n,
+        "steps": steps,
+        "warmup": warmup,
         "ms_per_step": round(ms_step, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u8",
-        "data": f"synthetic {args.kind} bytes, seed {args.seed}+rank, generated in HBM",
-        "config": {
-            "workload": (f"{gib:g} GiB {args.kind} stream per GPU x {world} GPU: histogram + host "
-                         "codebook + encode + gap-array decode"),
-            "bytes_per_gpu": n,
-            "chunk_syms": cs,
-            "enc_mode": "planned" if batch_hist is not None else args.enc_mode,
-            "compressed_ratio": round(C / n, 4),
-            "max_code_len": int(state["lens"].max()),
-            "gather_to_root": bool(args.gather),
-        },
+        "value": round(n * world / (elapsed / steps) / 1e9, 2),
+        "unit": "GB/s",
         "roundtrip_ok": ok,
-        "encode_GBps_uncompressed": round(n / (enc_ms * 1e-3) / 1e9, 1),
-        "decode_GBps_uncompressed": round(n / (dec_ms * 1e-3) / 1e9, 1),
+        "compressed_ratio": round(C / n, 4),
+        "max_code_len": maxlen,
+        "ties": tie_count(state["hist"]),
+        "encode_GBps_uncompressed": round(n / (kern_ms["encode"] * 1e-3) / 1e9, 1),
+        "decode_GBps_uncompressed": round(n / (kern_ms["decode"] * 1e-3) / 1e9, 1),
         "histogram_GBps": round(kernels["histogram"]["GBps"], 1),
         "kernel_ms": {k: round(v["ms"], 4) for k, v in kernels.items()},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "hbm_frac": {k: round(v["GBps"] / HBM_PEAK_GBPS, 4) for k, v in kernels.items()},
         "roofline": roofline,
     }
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(data, args.cpu_sample_mib)
-    if rank == 0:
-        if json_fd is not None:
-            sys.stdout.flush()
-            os.write(json_fd, (json.dumps(result) + "\n").encode())
-        else:
-            print(json.dumps(result), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if not ok:
-        raise SystemExit("round trip mismatch")
+    if use_dist and state["plan"] is not None:
+        rec["stream_total_bytes"] = state["plan"].total_bytes
+    env["last_data"] = data if not use_dist else None
+    del out, bufs, batch_hist
+    return rec
 
 
 def pmc_traffic(kind: str, n: int, cs: int, kernel: str):
     """HBM bytes per launch of `kernel` from the PMC counters (FETCH_SIZE doubled
     as gfx950 needs, plus WRITE_SIZE), collected in separate rocprofv3 --pmc
-    passes on this workload and recorded in huffman_amd/pmc_traffic.json by
-    tools/make_traffic.py; None when this workload was not profiled."""
+    passes over this same workload and recorded in huffman_amd/pmc_traffic.json by
+    tools/make_traffic.py -- a recorded figure, not a measurement of this run;
+    (None, None) when this workload was not profiled."""
     try:
         with open(os.path.join(ROOT, "huffman_amd", "pmc_traffic.json")) as f:
             table = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, None
     entry = table.get(f"{kind}:{n}:{cs}")
-    return entry.get(kernel) if entry else None
+    if not entry or kernel not in entry:
+        return None, None
+    return entry[kernel], entry.get("source")
 
 
-def cpu_baseline(data: torch.Tensor, sample_mib: int) -> dict:
+def cpu_baseline(data, sample_mib: int) -> dict:
     """The CPU restatement of the reference (oracle/oracle.c), single thread, on
     the leading sample of the same stream: from_slice + write + flush + read."""
+    import numpy as np
+
     import oracle
 
     oracle.build()
@@ -323,6 +333,123 @@ def cpu_baseline(data: torch.Tensor, sample_mib: int) -> dict:
         "encode_GBps": round(m / (t2 - t0) / 1e9, 4),
         "decode_GBps": round(m / (t3 - t2) / 1e9, 4),
     }
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    # HF_BENCH_FORCE_DIST=1 runs the collectives with a single rank too (a
+    # rehearsal of the multi-GPU code path on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("HF_BENCH_FORCE_DIST") == "1"
+    json_fd = None
+    rccl_world = None
+    if use_dist:
+        import torch.distributed as dist  # noqa: F811
+
+        # RCCL prints a version banner on stdout when its first communicator
+        # comes up: everything but the result line goes to stderr instead
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        dist.init_process_group("nccl", device_id=dev)
+        rccl_world = dist.get_world_size()
+    env = {"dev": dev, "dist": dist, "rank": rank, "world": world}
+
+    single = args.kind is not None or args.gib is not None
+    kind = args.kind or "zipf"
+    if world > 1 or (use_dist and not single):
+        # one logical stream of --total-gib, cut into contiguous shards
+        gib = args.gib if args.gib is not None else args.total_gib / world
+        steps = args.steps if args.steps is not None else 20
+        warmup = args.warmup if args.warmup is not None else 3
+        scaling = "strong" if args.gib is None else "weak"
+    else:
+        gib = args.gib if args.gib is not None else 1.0
+        steps = args.steps if args.steps is not None else 100
+        warmup = args.warmup if args.warmup is not None else 10
+        scaling = "weak"
+    n = int(gib * GIB)
+
+    head = run_workload(args, env, kind, n, steps, warmup)
+    result = {
+        "metric": "encode+decode GB/s (uncompressed)",
+        "value": head["value"],
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": scaling,
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": f"synthetic {kind} bytes, seed {args.seed}+rank, generated in HBM",
+        "config": {
+            "workload": (f"one {gib * world:g} GiB {kind} stream in {world} contiguous shard(s) of "
+                         f"{gib:g} GiB, one per GPU: counting pass + host codebook + encode + "
+                         "gap-array decode"),
+            "bytes_per_gpu": n,
+            "total_bytes": n * world,
+            "chunk_syms": args.chunk_syms,
+            "enc_mode": "planned" if not args.no_plan else args.enc_mode,
+            "compressed_ratio": head["compressed_ratio"],
+            "max_code_len": head["max_code_len"],
+            "ties": head["ties"],
+            "gather_to_root": bool(args.gather),
+        },
+        "roundtrip_ok": head["roundtrip_ok"],
+    }
+    if rccl_world is not None:
+        result["world_size"] = rccl_world
+        result["collectives"] = "RCCL all-gather of the 256-bin histograms (merge + scan in one)"
+    for key in ("encode_GBps_uncompressed", "decode_GBps_uncompressed", "histogram_GBps",
+                "kernel_ms", "stage_ms", "hbm_frac", "roofline"):
+        result[key] = head[key]
+    if "stream_total_bytes" in head:
+        result["config"]["stream_total_bytes"] = head["stream_total_bytes"]
+    ok = head["roundtrip_ok"]
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and env.get("last_data") is not None:
+        result["cpu_baseline"] = cpu_baseline(env["last_data"], args.cpu_sample_mib)
+    env["last_data"] = None
+    torch.cuda.empty_cache()
+
+    if world == 1 and not use_dist and not single and not args.no_extra_configs:
+        # the other single-GPU configurations, each with fewer steps as the streams grow
+        subs = []
+        for sub_kind, sub_gib, sub_steps in (("uniform", 1, 30), ("geometric", 4, 10),
+                                             ("zipf", 16, 5)):
+            rec = run_workload(args, env, sub_kind, int(sub_gib * GIB), sub_steps, 2)
+            env["last_data"] = None
+            torch.cuda.empty_cache()
+            ok = ok and rec["roundtrip_ok"]
+            subs.append(rec)
+        result["configs"] = subs
+
+    if rank == 0:
+        line = json.dumps(result)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (line + "\n").encode())
+        else:
+            print(line, flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("round trip mismatch")
 
 
 if __name__ == "__main__":

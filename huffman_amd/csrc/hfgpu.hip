@@ -35,6 +35,12 @@ struct hf_ctx {
     char err[512] = {0};
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // The scratch block is shared by every call on this context, whatever stream
+    // the caller has bound: `scratch_done` is recorded behind the last kernel
+    // that uses it, and a call on another stream waits for that event first.
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_busy = false;
     uint64_t *d_result = nullptr; // result block of the synchronous entry points
     int num_cus = 256;
     int enc_mode = 1;
@@ -125,19 +131,61 @@ int fail(hf_ctx *ctx, int status, const char *fmt, ...)
             return fail((ctx), HF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));    \
     } while (0)
 
-int ensure_scratch(hf_ctx *ctx, size_t bytes)
-{
-    if (bytes <= ctx->scratch_bytes)
-        return HF_OK;
-    if (ctx->scratch) {
-        HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        HF_HIP(ctx, hipFree(ctx->scratch));
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
+// Makes the thread's current device the context's for the lifetime of the
+// guard: every entry point that reaches the HIP runtime starts with one, so a
+// process that holds contexts for several GPUs allocates and launches on the
+// right one and finds its own current device unchanged afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const hf_ctx *ctx)
+    {
+        if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device)
+            switched = hipSetDevice(ctx->device) == hipSuccess;
     }
-    size_t want = std::max(bytes, (size_t)1 << 20);
-    HF_HIP(ctx, hipMalloc(&ctx->scratch, want));
-    ctx->scratch_bytes = want;
+    ~DeviceGuard()
+    {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// The context's scratch block with at least `bytes` bytes, ordered behind its
+// previous user: work queued on another stream may still be reading or writing
+// it, so the context's current stream waits for the event that user left (the
+// same stream is ordered already), and the block is only freed for a larger
+// one once that event has passed.  Every user calls scratch_release() after
+// its last kernel that touches the block.
+int scratch_acquire(hf_ctx *ctx, size_t bytes)
+{
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) {
+            if (ctx->scratch_busy)
+                HF_HIP(ctx, hipEventSynchronize(ctx->scratch_done));
+            HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            HF_HIP(ctx, hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+            ctx->scratch_busy = false;
+        }
+        size_t want = std::max(bytes, (size_t)1 << 20);
+        HF_HIP(ctx, hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    if (ctx->scratch_busy && ctx->scratch_stream != ctx->stream)
+        HF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->scratch_done, 0));
+    return HF_OK;
+}
+
+int scratch_release(hf_ctx *ctx)
+{
+    if (!ctx->scratch_done)
+        HF_HIP(ctx, hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
+    HF_HIP(ctx, hipEventRecord(ctx->scratch_done, ctx->stream));
+    ctx->scratch_stream = ctx->stream;
+    ctx->scratch_busy = true;
     return HF_OK;
 }
 
@@ -184,7 +232,6 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     const size_t off_ksyms = off_keys + 256 * sizeof(uint64_t);
     const size_t off_klens = off_ksyms + 256;
     const size_t total = off_klens + 256;
-    HF_HIP(ctx, hipSetDevice(ctx->device));
     hf_ctx::Pinned &ps = ctx->pinned[ctx->pinned_next++ % 4];
     if (ps.used)
         HF_HIP(ctx, hipEventSynchronize(ps.done)); // the copy that last read this buffer is over
@@ -335,8 +382,15 @@ int hf_ctx_create(int device, hf_ctx **out)
     if (!ctx)
         return HF_ERR_INTERNAL;
     ctx->device = device;
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
+        delete ctx;
+        return HF_ERR_HIP;
+    }
+    DeviceGuard on(ctx); // the caller's current device is left as it was
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess || cur != device) {
         delete ctx;
         return HF_ERR_HIP;
     }
@@ -354,12 +408,14 @@ int hf_ctx_create(int device, hf_ctx **out)
 
 int hf_ctx_destroy(hf_ctx *ctx)
 {
+    DeviceGuard on(ctx);
     if (!ctx)
         return HF_OK;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize(); // work on any stream may still use the blocks freed below
     if (ctx->scratch)
         (void)hipFree(ctx->scratch);
+    if (ctx->scratch_done)
+        (void)hipEventDestroy(ctx->scratch_done);
     if (ctx->arena)
         (void)hipFree(ctx->arena);
     for (auto &b : ctx->blob_cache)
@@ -395,6 +451,7 @@ int hf_ctx_set_stream(hf_ctx *ctx, void *stream)
 
 int hf_ctx_synchronize(hf_ctx *ctx)
 {
+    DeviceGuard on(ctx);
     if (!ctx)
         return HF_ERR_BAD_ARG;
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -403,6 +460,7 @@ int hf_ctx_synchronize(hf_ctx *ctx)
 
 int hf_ctx_kernel_ms(hf_ctx *ctx, int kind, double *sum_ms, uint64_t *launches)
 {
+    DeviceGuard on(ctx);
     if (!ctx || kind < 0 || kind > 2 || !sum_ms || !launches)
         return HF_ERR_BAD_ARG;
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -448,6 +506,7 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
 
 int hf_histogram_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d_hist)
 {
+    DeviceGuard on(ctx);
     if (!ctx || !d_hist || (!d_in && n))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram: null pointer");
     if (n >= (1ull << 40))
@@ -474,6 +533,7 @@ uint64_t hf_batch_hist_bytes(uint64_t n)
 int hf_histogram_batches_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d_hist,
                                uint32_t *d_batch_hist)
 {
+    DeviceGuard on(ctx);
     if (!ctx || !d_hist || (!d_in && n) || (!d_batch_hist && n))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram_batches: null pointer");
     if (n >= (1ull << 40))
@@ -499,7 +559,8 @@ int hf_histogram(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t hist[256
 {
     if (!ctx || !hist)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram: null pointer");
-    int rc = ensure_scratch(ctx, 256 * sizeof(uint64_t));
+    DeviceGuard on(ctx);
+    int rc = scratch_acquire(ctx, 256 * sizeof(uint64_t));
     if (rc != HF_OK)
         return rc;
     uint64_t *d_hist = static_cast<uint64_t *>(ctx->scratch);
@@ -509,6 +570,7 @@ int hf_histogram(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t hist[256
     HF_HIP(ctx, hipMemcpyAsync(hist, d_hist, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->scratch_busy = false; // everything that used the block has completed
     return HF_OK;
 }
 
@@ -517,6 +579,7 @@ int hf_histogram(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t hist[256
 int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[256],
                     hf_model **out)
 {
+    DeviceGuard on(ctx);
     if (!ctx || !codes || !lens || !out)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_model_create: null pointer");
     *out = nullptr;
@@ -576,6 +639,7 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
 int hf_model_from_table(hf_ctx *ctx, const uint64_t *keys, const uint8_t *syms,
                         const uint8_t *klens, uint64_t m, uint64_t sentinel, hf_model **out)
 {
+    DeviceGuard on(ctx);
     if (!ctx || !keys || !syms || !klens || !out)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_model_from_table: null pointer");
     *out = nullptr;
@@ -619,8 +683,8 @@ int hf_model_destroy(hf_model *model)
 {
     if (!model)
         return HF_OK;
+    DeviceGuard on(model->ctx);
     if (model->d_blob) {
-        (void)hipSetDevice(model->ctx->device);
         // Kernels that read the tables may still be queued.  The block is kept
         // for the next model, whose upload is ordered behind them on the same
         // stream; only tables that other streams have used need a full wait.
@@ -660,11 +724,15 @@ int hf_gap_layout(uint64_t n, uint32_t chunk_syms, uint64_t *n_chunks, uint64_t 
 namespace {
 
 // hf_encode_async and hf_encode_planned_async (d_batch_hist != null)
+// `fixed_scratch` / `fixed_bytes`: a caller-supplied scratch block that replaces
+// the context's growable one (then nothing is allocated and no kernel is timed).
 int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
                   uint32_t lead_bits, const uint32_t *d_batch_hist, uint8_t *d_out,
                   uint64_t out_cap, uint32_t chunk_syms, uint16_t *d_chunk_bits,
-                  uint64_t *d_seg_off, uint64_t *d_result)
+                  uint64_t *d_seg_off, uint64_t *d_result, void *fixed_scratch = nullptr,
+                  size_t fixed_bytes = 0)
 {
+    DeviceGuard on(ctx);
     if (!ctx || !model || !d_result || (!d_in && n) || (!d_out && out_cap))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode: null pointer");
     if (!model->has_encode)
@@ -719,9 +787,18 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         p.debug &= ~16u; // the phase trace overwrites the tail of the output buffer
 
     const size_t need = ((size_t)n_tiles + 4) * sizeof(uint64_t);
-    int rc = ensure_scratch(ctx, need);
-    if (rc != HF_OK)
-        return rc;
+    void *work = fixed_scratch;
+    if (fixed_scratch) {
+        if (need > fixed_bytes)
+            return fail(ctx, HF_ERR_UNSUPPORTED,
+                        "hf_encode: %llu symbols need %zu bytes of scratch, the fixed block has %zu",
+                        (unsigned long long)n, need, fixed_bytes);
+    } else {
+        int rc = scratch_acquire(ctx, need);
+        if (rc != HF_OK)
+            return rc;
+        work = ctx->scratch;
+    }
     // codes merged per append, and whether the table flags codes too long for that
     const int g = model->enc_group;
     const bool flagged = model->enc_spec;
@@ -736,7 +813,7 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
     if (planned) {
         // scratch: group offsets (+ total) | start inside the group | bit total, per batch
         const uint32_t n_groups = (n_batches + ENC_WAVES - 1) / ENC_WAVES;
-        uint64_t *off = static_cast<uint64_t *>(ctx->scratch);
+        uint64_t *off = static_cast<uint64_t *>(work);
         uint32_t *local = reinterpret_cast<uint32_t *>(off + n_groups + 1);
         uint32_t *tot = local + n_batches;
         hipLaunchKernelGGL(enc_plan_bits_kernel, dim3(n_groups), dim3(ENC_THREADS), 0, ctx->stream,
@@ -747,14 +824,14 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         p.plan_local = local;
         p.plan_tot = tot;
     } else if (!chained) {
-        p.tile_off = static_cast<uint64_t *>(ctx->scratch);
+        p.tile_off = static_cast<uint64_t *>(work);
         hipLaunchKernelGGL(enc_tile_bits_kernel, dim3(n_tiles), dim3(ENC_THREADS), 0, ctx->stream,
                            p);
         hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, p.tile_off,
                            n_tiles, d_result);
     } else {
-        HF_HIP(ctx, hipMemsetAsync(ctx->scratch, 0, need, ctx->stream));
-        p.desc = static_cast<unsigned long long *>(ctx->scratch);
+        HF_HIP(ctx, hipMemsetAsync(work, 0, need, ctx->stream));
+        p.desc = static_cast<unsigned long long *>(work);
         p.ticket = reinterpret_cast<uint32_t *>(p.desc + n_batches);
         p.abort_flag = p.ticket + 2;
     }
@@ -775,7 +852,7 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         kern = g == 4 ? HF_PICK(4) : (g == 2 ? HF_PICK(2) : HF_PICK(1));
 #undef HF_PICK
         // (only the launch over the complete batches is timed: the ragged rest is one workgroup)
-        if (lean)
+        if (lean && !fixed_scratch)
             HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE,
                             hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), 0, ctx->stream, p));
         else
@@ -784,6 +861,8 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
             p.ticket += 1;
     }
     HF_HIP(ctx, hipGetLastError());
+    if (!fixed_scratch)
+        return scratch_release(ctx);
     return HF_OK;
 }
 
@@ -816,6 +895,7 @@ int hf_encode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
               uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,
               uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint64_t *total_bits)
 {
+    DeviceGuard on(ctx);
     if (!ctx)
         return HF_ERR_BAD_ARG;
     int rc = hf_encode_async(ctx, model, d_in, n, lead_bits, d_out, out_cap, chunk_syms,
@@ -838,8 +918,9 @@ int hf_encoder_write_value(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, const u
     if (n > HF_WRITE_VALUE_MAX)
         return fail(ctx, HF_ERR_UNSUPPORTED, "hf_encoder_write_value: more than %llu symbols",
                     (unsigned long long)HF_WRITE_VALUE_MAX);
+    DeviceGuard on(ctx);
     const size_t bytes = (512 + 3 + 2) * sizeof(uint64_t);
-    int rc = ensure_scratch(ctx, bytes);
+    int rc = scratch_acquire(ctx, bytes);
     if (rc != HF_OK)
         return rc;
     uint64_t host[512 + 3 + 2];
@@ -855,6 +936,7 @@ int hf_encoder_write_value(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, const u
     HF_HIP(ctx, hipMemcpyAsync(host + 512, d + 512, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->scratch_busy = false;
     if (host[516])
         return fail(ctx, HF_ERR_CODELEN, "Codelen > 64");
     std::memcpy(state, host + 512, 3 * sizeof(uint64_t));
@@ -899,6 +981,7 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
                     const uint16_t *d_chunk_bits, const uint64_t *d_seg_off, uint8_t *d_out,
                     uint64_t *d_result)
 {
+    DeviceGuard on(ctx);
     DecParams p{};
     int rc = fill_dec_params(ctx, model, d_in, in_bytes, bit_base, n_out, d_out, d_result, &p);
     if (rc != HF_OK)
@@ -922,8 +1005,17 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     const int spr = model->sentinel <= 8 ? 4 : (model->sentinel <= 16 ? 2 : 1);
     void (*kern)(DecParams) = nullptr;
     size_t lds = 0;
-    const bool reg128 = chunk_syms == 128 && !model->lut_escapes;
-    const bool reg256 = chunk_syms == 256 && !model->lut_escapes;
+    // symbols per window rebuild of the register-output kernel: K * sentinel <= 64
+    // (or the model's speculative K).  Its instantiations for tables without
+    // escape entries start at K = 5; a table whose codes are all short enough
+    // for the first level but whose sentinel leaves k < 5 (few, long, aligned
+    // codes) takes the K = 1..4 instantiations, which exist with the escape
+    // test compiled in (the test is then simply never taken), and the
+    // BitReader kernel for the larger chunk sizes.
+    const uint32_t k = 64u / std::max<uint32_t>(model->sentinel, 1u);
+    const bool short_k = k < 5 && model->dec_spec_k <= k;
+    const bool reg128 = chunk_syms == 128 && !model->lut_escapes && !short_k;
+    const bool reg256 = chunk_syms == 256 && !model->lut_escapes && !short_k;
     if ((chunk_syms == 64 || reg128 || reg256) && !(ctx->debug & 256)) {
         // register-output kernel: one LDS image serves as input, then as output
         const uint32_t in_raw = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
@@ -931,8 +1023,6 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
         const uint32_t out_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
         p.istg_words = std::max(in_words, out_words);
         lds = lut_bytes + (size_t)(p.istg_words + 4) * 4;
-        // symbols per window rebuild: K * sentinel <= 64, or the model's speculative K
-        const uint32_t k = 64u / std::max<uint32_t>(model->sentinel, 1u);
         if (reg256) // 64 output registers per lane, two work-groups per CU
             kern = model->regular_chunks
                        ? (k >= 6 ? dec_kernel_reg<256, 6, false, true, false>
@@ -957,7 +1047,7 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
                                 : (sk >= 8 ? dec_kernel_reg<64, 8, false, false, true>
                                            : (sk == 7 ? dec_kernel_reg<64, 7, false, false, true>
                                                       : dec_kernel_reg<64, 6, false, false, true>));
-        } else if (model->lut_escapes)
+        } else if (model->lut_escapes || short_k)
             kern = k >= 4 ? dec_kernel_reg<64, 4, true, false, false>
                           : (k == 3 ? dec_kernel_reg<64, 3, true, false, false>
                                     : (k == 2 ? dec_kernel_reg<64, 2, true, false, false>
@@ -997,6 +1087,7 @@ int hf_decode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
               uint64_t bit_base, uint64_t n_out, uint32_t chunk_syms,
               const uint16_t *d_chunk_bits, const uint64_t *d_seg_off, uint8_t *d_out)
 {
+    DeviceGuard on(ctx);
     if (!ctx)
         return HF_ERR_BAD_ARG;
     int rc = hf_decode_async(ctx, model, d_in, in_bytes, bit_base, n_out, chunk_syms, d_chunk_bits,
@@ -1012,6 +1103,7 @@ int hf_decode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
 int hf_decode_serial(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
                      uint64_t bit_base, uint64_t n_out, uint8_t *d_out)
 {
+    DeviceGuard on(ctx);
     if (!ctx)
         return HF_ERR_BAD_ARG;
     DecParams p{};
@@ -1035,6 +1127,7 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
                        uint64_t n_out, uint32_t chunk_syms, uint16_t *d_chunk_bits,
                        uint64_t *d_seg_off)
 {
+    DeviceGuard on(ctx);
     if (!ctx)
         return HF_ERR_BAD_ARG;
     if (!valid_chunk_syms(chunk_syms))
@@ -1072,7 +1165,7 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
     const size_t o_start = take(g.n_sub), o_exit = take(g.n_sub), o_cnt = take(g.n_sub * 4);
     const size_t o_in = take(g.n_wg * 4), o_used = take(g.n_wg * 4), o_chg = take(4);
     const size_t o_base = take((g.n_wg + 1) * 8), o_s32 = take((g.n_chunks + 1) * 4);
-    rc = ensure_scratch(ctx, off);
+    rc = scratch_acquire(ctx, off);
     if (rc != HF_OK)
         return rc;
     uint8_t *b = static_cast<uint8_t *>(ctx->scratch);
@@ -1125,6 +1218,7 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
     uint64_t res[HF_RES_WORDS];
     HF_HIP(ctx, hipMemcpyAsync(res, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->scratch_busy = false;
     return flags_to_status(ctx, res[HF_RES_FLAGS]);
 }
 
@@ -1333,6 +1427,7 @@ extern "C" {
 
 int hf_histogram_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n, uint64_t hist[256])
 {
+    DeviceGuard on(ctx);
     if (!ctx || !hist || (!h_in && n))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_histogram_host: null pointer");
     int rc = ensure_arena(ctx, n + 16);
@@ -1347,6 +1442,7 @@ int hf_encode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
                    uint32_t lead_bits, uint8_t *h_out, uint64_t out_cap, uint32_t chunk_syms,
                    uint16_t *h_chunk_bits, uint64_t *h_seg_off, uint64_t *total_bits)
 {
+    DeviceGuard on(ctx);
     if (!ctx || !model || (!h_in && n) || (!h_out && out_cap))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_host: null pointer");
     if ((h_chunk_bits == nullptr) != (h_seg_off == nullptr))
@@ -1400,6 +1496,7 @@ int hf_compress_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n, uint64_t code
                      uint64_t lens[256], uint8_t *h_out, uint64_t out_cap, uint32_t chunk_syms,
                      uint16_t *h_chunk_bits, uint64_t *h_seg_off, uint64_t *total_bits)
 {
+    DeviceGuard on(ctx);
     if (!ctx || !codes || !lens || !total_bits || (!h_in && n) || (!h_out && out_cap))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_compress_host: null pointer");
     if ((h_chunk_bits == nullptr) != (h_seg_off == nullptr))
@@ -1486,6 +1583,7 @@ int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
                    uint64_t n_out, uint32_t chunk_syms, const uint16_t *h_chunk_bits,
                    const uint64_t *h_seg_off, uint8_t *h_out)
 {
+    DeviceGuard on(ctx);
     if (!ctx || !model || (!h_in && in_bytes) || (!h_out && n_out))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_host: null pointer");
     if ((h_chunk_bits == nullptr) != (h_seg_off == nullptr))
@@ -1553,6 +1651,7 @@ int hf_encoder_write_value_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n,
                                 const uint64_t codes[256], const uint64_t lens[256],
                                 uint64_t state[3], uint64_t *ret)
 {
+    DeviceGuard on(ctx);
     if (!ctx || (!h_in && n))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encoder_write_value_host: null pointer");
     if (n > HF_WRITE_VALUE_MAX)

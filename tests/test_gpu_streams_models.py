@@ -1,0 +1,140 @@
+"""GPU tests of the library's own bookkeeping: calls in flight on several
+streams that share the context's scratch block, models whose tables select the
+decoder's rarely used instantiations, contexts on a device that is not the
+thread's current one.  All results are compared bit-exactly with the CPU
+oracle, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from huffman_amd import synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (there is no CPU fallback)")
+    from huffman_amd import device
+
+    return device
+
+
+def to_gpu(a: np.ndarray):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_encodes_in_flight_on_two_streams_share_the_scratch_block(dev, orc):
+    """Two chained and two planned encodes are queued back to back on two
+    streams without a host synchronisation in between.  They all use the one
+    scratch block of the context (look-back descriptors and tickets, or the
+    plan arrays): the library has to order them, whatever the streams do."""
+    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cases = []
+    for i, (kind, n) in enumerate([("zipf", (9 << 20) + 12345), ("uniform", (6 << 20) + 77),
+                                   ("geometric", (11 << 20) + 3), ("testfile", (7 << 20) + 65536)]):
+        data = synth.generate_host(kind, n, seed=500 + i)
+        codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+        want, _ = orc.encode_slice(data, codes, lens)
+        t = to_gpu(data)
+        model = dev.DeviceModel(codes, lens)
+        bufs = dev.EncodeBuffers(model, n)
+        bh = dev.new_batch_hist(n, t.device) if i >= 2 else None
+        cases.append((data, want, t, model, bufs, bh, codes, lens))
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        for i, (data, want, t, model, bufs, bh, codes, lens) in enumerate(cases):
+            bufs.data.zero_()
+        torch.cuda.synchronize()
+        for i, (data, want, t, model, bufs, bh, codes, lens) in enumerate(cases):
+            with torch.cuda.stream(s[(i + rnd) % 2]):
+                if bh is not None:
+                    dev.histogram_async(t, batch_hist=bh)
+                dev.encode_async(t, model, bufs, plan=bh)
+        torch.cuda.synchronize()
+        for data, want, t, model, bufs, bh, codes, lens in cases:
+            bits, flags = bufs.result.tolist()[:2]
+            assert flags == 0
+            assert bits == int(np.asarray(lens, dtype=np.uint64)[data].sum())
+            assert np.array_equal(bufs.data[: want.size].cpu().numpy(), want)
+
+
+def test_sync_call_on_another_stream_waits_for_an_encode_in_flight(dev, orc):
+    """hf_histogram keeps its result in the same scratch block: called on a
+    second stream while a chained encode is still running on the first, it
+    must not overwrite that encode's descriptors."""
+    n = (24 << 20) + 1001
+    data = synth.generate_host("zipf", n, seed=77)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    want, _ = orc.encode_slice(data, codes, lens)
+    t = to_gpu(data)
+    small = to_gpu(data[:100000])
+    model = dev.DeviceModel(codes, lens)
+    bufs = dev.EncodeBuffers(model, n)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            dev.encode_async(t, model, bufs)
+        with torch.cuda.stream(s2):
+            h = dev.histogram(small)
+        torch.cuda.synchronize()
+        assert np.array_equal(h, orc.histogram(data[:100000]))
+        assert bufs.result.tolist()[:2] == [int(np.asarray(lens, dtype=np.uint64)[data].sum()), 0]
+        assert np.array_equal(bufs.data[: want.size].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("chunk_syms", [64, 128, 256])
+@pytest.mark.parametrize("width,nsym", [(16, 2), (16, 5), (20, 3), (13, 4), (32, 2), (22, 8)])
+def test_fixed_length_long_codes_decode(dev, orc, chunk_syms, width, nsym):
+    """A few fixed-length codes of 13..32 bits whose keys are multiples of
+    2^(width - 11): the first-level table resolves every one of them (no
+    escape entries), yet fewer than five fit a 64-bit window."""
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    step = (1 << width) // nsym
+    step -= step % (1 << (width - 11))
+    for i in range(nsym):
+        codes[10 + i] = i * step
+        lens[10 + i] = width
+    rng = np.random.default_rng(width * 100 + nsym)
+    n = 70000 + chunk_syms + 3
+    data = (10 + rng.integers(0, nsym, size=n)).astype(np.uint8)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model, chunk_syms=chunk_syms)
+    want, _ = orc.encode_slice(data, codes, lens)
+    stream = enc.stream().cpu().numpy()
+    assert np.array_equal(stream, want)
+    got = dev.decode(enc, model).cpu().numpy()
+    assert np.array_equal(got, orc.decode_read(stream, codes, lens, n))
+    assert np.array_equal(got, data)
+    # the same through a decode-only model built from the key table
+    keys, syms, kl = orc.to_btreemap(codes, lens)
+    dmodel = dev.DeviceModel(table=(keys, syms, kl, orc.sentinel(lens)))
+    assert np.array_equal(dev.decode(enc, dmodel).cpu().numpy(), data)
+
+
+def test_context_calls_leave_the_current_device_alone(dev, orc):
+    """Every entry point switches to its context's device for the call only."""
+    from huffman_amd._lib import lib
+
+    before = torch.cuda.current_device()
+    h = C.c_void_p()
+    assert lib().hf_ctx_create(before, C.byref(h)) == 0
+    assert torch.cuda.current_device() == before
+    # a device that does not exist is refused, and nothing changes
+    bad = C.c_void_p()
+    assert lib().hf_ctx_create(torch.cuda.device_count(), C.byref(bad)) != 0
+    assert torch.cuda.current_device() == before
+    data = synth.generate_host("zipf", 50000, seed=9)
+    t = to_gpu(data)
+    hist = np.zeros(256, dtype=np.uint64)
+    assert lib().hf_histogram(h, t.data_ptr(), t.numel(),
+                              hist.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    assert np.array_equal(hist, orc.histogram(data))
+    assert lib().hf_ctx_destroy(h) == 0
+    assert torch.cuda.current_device() == before
