@@ -28,6 +28,7 @@ HF_ERR_UNSUPPORTED = 9
 HF_RES_WORDS = 4
 HF_SEG_CHUNKS = 256
 HF_PLAN_BATCH = 65536
+HF_NOALLOC_MAX_SYMBOLS = 1 << 32
 
 # every symbol include/hfgpu.h declares, with its signature
 SIGNATURES = {
@@ -62,6 +63,9 @@ SIGNATURES = {
                                   C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "hf_encode_planned_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hf_encode_noalloc_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hf_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,

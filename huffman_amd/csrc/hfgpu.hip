@@ -27,6 +27,14 @@
 #include "kern_decode.hpp"
 #include "kern_gap.hpp"
 
+// Scratch of hf_encode_noalloc_async: a fixed block in the code object's own
+// device memory, so that entry point never calls the allocator.  Every GPU the
+// library runs on holds its own copy at its own address for the life of the
+// process.  In host code the array's name is only a handle for
+// hipGetSymbolAddress: hf_ctx_create resolves the address on the context's
+// device and everything else goes through that pointer.
+static __device__ __align__(256) unsigned char scratch[HF_NOALLOC_SCRATCH_BYTES];
+
 // ===================================================================== host
 
 struct hf_ctx {
@@ -42,6 +50,7 @@ struct hf_ctx {
     hipStream_t scratch_stream = nullptr;
     bool scratch_busy = false;
     uint64_t *d_result = nullptr; // result block of the synchronous entry points
+    void *fixed_scratch = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress)
     int num_cus = 256;
     int enc_mode = 1;
     int hist_grid = 0;
@@ -399,6 +408,13 @@ int hf_ctx_create(int device, hf_ctx **out)
         ctx->num_cus = prop.multiProcessorCount;
     e = hipMalloc(reinterpret_cast<void **>(&ctx->d_result), HF_RES_WORDS * sizeof(uint64_t));
     if (e != hipSuccess) {
+        delete ctx;
+        return HF_ERR_HIP;
+    }
+    // this device's address of the fixed scratch block (the device is current here)
+    e = hipGetSymbolAddress(&ctx->fixed_scratch, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ctx->fixed_scratch) {
+        (void)hipFree(ctx->d_result);
         delete ctx;
         return HF_ERR_HIP;
     }
@@ -889,6 +905,25 @@ int hf_encode_planned_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_planned: d_batch_hist must be 16-byte aligned");
     return encode_launch(ctx, model, d_in, n, lead_bits, d_batch_hist, d_out, out_cap, chunk_syms,
                          d_chunk_bits, d_seg_off, d_result);
+}
+
+int hf_encode_noalloc_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
+                            uint32_t lead_bits, const uint32_t *d_batch_hist, uint8_t *d_out,
+                            uint64_t out_cap, uint32_t chunk_syms, uint16_t *d_chunk_bits,
+                            uint64_t *d_seg_off, uint64_t *d_result)
+{
+    if (!ctx)
+        return HF_ERR_BAD_ARG;
+    if (n > HF_NOALLOC_MAX_SYMBOLS)
+        return fail(ctx, HF_ERR_UNSUPPORTED,
+                    "hf_encode_noalloc: %llu symbols exceed the fixed scratch block's limit of %llu",
+                    (unsigned long long)n, (unsigned long long)HF_NOALLOC_MAX_SYMBOLS);
+    if ((uintptr_t)d_batch_hist & 15)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_noalloc: d_batch_hist must be 16-byte aligned");
+    // the kernels get the block's device address, never the array's name
+    return encode_launch(ctx, model, d_in, n, lead_bits, d_batch_hist, d_out, out_cap, chunk_syms,
+                         d_chunk_bits, d_seg_off, d_result, ctx->fixed_scratch,
+                         HF_NOALLOC_SCRATCH_BYTES);
 }
 
 int hf_encode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,

@@ -240,6 +240,21 @@ def encode_async(t: torch.Tensor, model: DeviceModel, bufs: EncodeBuffers,
                                                 bufs.result.data_ptr()))
 
 
+def encode_noalloc_async(t: torch.Tensor, model: DeviceModel, bufs: EncodeBuffers,
+                         lead_bits: int = 0, plan: torch.Tensor | None = None) -> None:
+    """encode_async through the entry point that allocates nothing: its scratch is
+    a fixed block inside the library (at most HF_NOALLOC_MAX_SYMBOLS symbols;
+    calls that overlap in time on one GPU race)."""
+    ctx = model.ctx
+    ctx.bind_stream()
+    cb = bufs.chunk_bits.data_ptr() if bufs.chunk_bits is not None else None
+    so = bufs.seg_off.data_ptr() if bufs.seg_off is not None else None
+    ctx.check(lib().hf_encode_noalloc_async(ctx.handle, model.handle, t.data_ptr(), t.numel(),
+                                            lead_bits, plan.data_ptr() if plan is not None else None,
+                                            bufs.data.data_ptr(), bufs.cap, bufs.chunk_syms, cb,
+                                            so, bufs.result.data_ptr()))
+
+
 def encode(t: torch.Tensor, model: DeviceModel, chunk_syms: int = DEFAULT_CHUNK_SYMS,
            lead_bits: int = 0, with_gap: bool = True, out_cap: int | None = None) -> Encoded:
     """Encoder::write + flush over a device-resident slice (synchronous)."""

@@ -196,6 +196,27 @@ HF_API int hf_encode_planned_async(hf_ctx *ctx, const hf_model *model, const uin
                                    uint64_t out_cap, uint32_t chunk_syms,
                                    uint16_t *d_chunk_bits, uint64_t *d_seg_off,
                                    uint64_t *d_result);
+/* hf_encode_async (d_batch_hist == NULL) or hf_encode_planned_async (d_batch_hist
+ * given) for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  Same arguments, same stream, same gap array,
+ * same result block -- but the look-back descriptors / plan arrays live in a
+ * fixed block of HF_NOALLOC_SCRATCH_BYTES that is part of the library's code
+ * object on every GPU, so the call reaches neither hipMalloc nor hipFree nor
+ * any other allocating routine, and it records no kernel timing.
+ *   - n above HF_NOALLOC_MAX_SYMBOLS is refused with HF_ERR_UNSUPPORTED.
+ *   - Every call on one GPU, from any context, uses that GPU's one block: two
+ *     calls that overlap in time on one GPU (different streams, no ordering
+ *     between them) race and corrupt each other's streams.  Calls on one
+ *     stream, or ordered by events, are fine; the block needs no clearing by
+ *     the caller. */
+#define HF_NOALLOC_MAX_SYMBOLS (1ull << 32)
+#define HF_NOALLOC_SCRATCH_BYTES ((HF_NOALLOC_MAX_SYMBOLS / 16384 + 4) * 8 + 224)
+HF_API int hf_encode_noalloc_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in,
+                                   uint64_t n, uint32_t lead_bits, const uint32_t *d_batch_hist,
+                                   uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,
+                                   uint16_t *d_chunk_bits, uint64_t *d_seg_off,
+                                   uint64_t *d_result);
 /* Synchronous form; *total_bits receives the bit count (lead_bits excluded). */
 HF_API int hf_encode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,
                      uint32_t lead_bits, uint8_t *d_out, uint64_t out_cap, uint32_t chunk_syms,
