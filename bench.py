@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="N=1: skip the uniform / geometric / 16 GiB sub-records")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    ap.add_argument("--lib-debug", type=int, default=0,
+                    help="the library's \"debug\" option (timing experiments: 64 = the other "
+                         "LDS image layout in the decoder, 128 = no two-symbol decode table)")
     ap.add_argument("--seed", type=int, default=2024)
     return ap.parse_args()
 
@@ -136,6 +139,7 @@ def run_workload(args, env, kind: str, n: int, steps: int, warmup: int) -> dict:
     ctx = hd.Context.get(dev)
     ctx.set_option("enc_mode", args.enc_mode)
     ctx.set_option("hist_grid", args.hist_grid)
+    ctx.set_option("debug", args.lib_debug)
     cs = args.chunk_syms
 
     d_hist = torch.empty(256, dtype=torch.int64, device=dev)
@@ -211,7 +215,7 @@ def run_workload(args, env, kind: str, n: int, steps: int, warmup: int) -> dict:
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=env["coll_dev"])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -219,7 +223,7 @@ def run_workload(args, env, kind: str, n: int, steps: int, warmup: int) -> dict:
     flags = int(bufs.result[1].item()) | int(dres[1].item())
     ok = flags == 0 and int(bufs.result[0].item()) == state["total_bits"] and torch.equal(out, data)
     if use_dist:
-        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=env["coll_dev"])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = bool(t.item())
 
@@ -347,6 +351,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    # HF_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives run over gloo
+    # on host tensors -- a rehearsal of the launcher, the shard plan and the
+    # strong-scaling bookkeeping on a one-GPU box (RCCL refuses two ranks on
+    # one device); its rates mean nothing
+    rehearse = os.environ.get("HF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -363,9 +374,13 @@ def main():
         sys.stdout.flush()
         json_fd = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         rccl_world = dist.get_world_size()
-    env = {"dev": dev, "dist": dist, "rank": rank, "world": world}
+    env = {"dev": dev, "dist": dist, "rank": rank, "world": world,
+           "coll_dev": torch.device("cpu") if rehearse else dev}
 
     single = args.kind is not None or args.gib is not None
     kind = args.kind or "zipf"
@@ -413,7 +428,8 @@ def main():
     }
     if rccl_world is not None:
         result["world_size"] = rccl_world
-        result["collectives"] = "RCCL all-gather of the 256-bin histograms (merge + scan in one)"
+        result["collectives"] = ("gloo on host tensors (rehearsal)" if rehearse else
+                                 "RCCL all-gather of the 256-bin histograms (merge + scan in one)")
     for key in ("encode_GBps_uncompressed", "decode_GBps_uncompressed", "histogram_GBps",
                 "kernel_ms", "stage_ms", "hbm_frac", "roofline"):
         result[key] = head[key]

@@ -291,22 +291,103 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
     return HF_OK;
 }
 
+bool is_prefix_free(const uint64_t *keys, const uint8_t *klens, uint64_t m, uint32_t sentinel)
+{
+    if (m == 0 || sentinel == 0 || sentinel > 64)
+        return false;
+    // with the keys (left-aligned codes) in ascending order, no key may fall
+    // inside the range its predecessor's code covers
+    for (uint64_t i = 0; i < m; ++i) {
+        if (klens[i] == 0 || klens[i] > sentinel)
+            return false;
+        if (i + 1 < m) {
+            const uint64_t span = (uint64_t)1 << (sentinel - klens[i]);
+            if (keys[i + 1] <= keys[i] || keys[i + 1] - keys[i] < span)
+                return false;
+        }
+    }
+    return true;
+}
+
+double build_pair_lut(const DecodeLut &lut, std::vector<uint32_t> *pair)
+{
+    const uint32_t w = lut.w1;
+    const uint32_t n = 1u << w;
+    pair->assign(n, HF_PAIR_SLOW | HF_PAIR_UNRESOLVED);
+    uint32_t slow = 0;
+    for (uint32_t x = 0; x < n; ++x) {
+        const uint16_t e0 = lut.pool[x];
+        const uint32_t l0 = e0 >> 8;
+        if ((e0 & 0x8000u) || l0 == 0 || l0 > w) {
+            ++slow;
+            continue;
+        }
+        // the bits behind the first code, zero filled: a second code that ends
+        // inside the index is resolved by the first level whatever the fill
+        const uint16_t e1 = lut.pool[(x << l0) & (n - 1)];
+        const uint32_t l1 = e1 >> 8;
+        if (l0 == w || (e1 & 0x8000u) || l1 == 0 || l0 + l1 > w) {
+            (*pair)[x] = HF_PAIR_SLOW | (uint32_t)(e0 & 0xffu) | (l0 << 16); // first symbol only
+            ++slow;
+            continue;
+        }
+        (*pair)[x] = (uint32_t)(e0 & 0xffu) | ((uint32_t)(e1 & 0xffu) << 8) | ((l0 + l1) << 16);
+    }
+    return (double)slow / (double)n;
+}
+
+bool prefer_padded_image(double mean_bits, double sd_bits)
+{
+    if (!(mean_bits > 0))
+        return false;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto uni = [&]() { // uniform in [0, 1)
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(rng >> 11) * (1.0 / 9007199254740992.0);
+    };
+    double cost[2] = {0, 0};
+    const int trials = 24;
+    for (int t = 0; t < trials; ++t) {
+        double start[32];
+        double at = uni() * 32.0 * 1024.0; // bit phase of the group's first chunk
+        for (int l = 0; l < 32; ++l) {
+            start[l] = at;
+            // sum of four uniforms: mean 2, variance 1/3
+            const double g = (uni() + uni() + uni() + uni() - 2.0) * 1.7320508;
+            at += std::max(1.0, mean_bits + sd_bits * g);
+        }
+        for (int padded = 0; padded < 2; ++padded) {
+            uint32_t word[32];
+            int worst = 1;
+            for (int l = 0; l < 32; ++l) {
+                const uint32_t w = (uint32_t)(start[l] / 32.0);
+                word[l] = padded ? w + (w >> 5) : w;
+            }
+            for (int l = 0; l < 32; ++l) {
+                int same_bank = 1;
+                for (int q = 0; q < l; ++q) // the same word is one access (broadcast)
+                    if ((word[q] & 31u) == (word[l] & 31u) && word[q] != word[l]) {
+                        bool counted = false;
+                        for (int r = 0; r < q; ++r)
+                            counted = counted || word[r] == word[q];
+                        if (!counted)
+                            ++same_bank;
+                    }
+                worst = std::max(worst, same_bank);
+            }
+            cost[padded] += worst;
+        }
+    }
+    return cost[1] + 0.4 * trials < cost[0];
+}
+
 uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t m,
                             uint32_t sentinel)
 {
     if (m == 0 || sentinel == 0 || sentinel > 64 || 8 * sentinel <= 64)
         return 0; // the plain K = 64 / sentinel is at least 8 wide already
-    // prefix free: with the keys (left-aligned codes) in ascending order, no key
-    // may fall inside the range its predecessor's code covers
-    for (uint64_t i = 0; i < m; ++i) {
-        if (klens[i] == 0 || klens[i] > sentinel)
-            return 0;
-        if (i + 1 < m) {
-            const uint64_t span = (uint64_t)1 << (sentinel - klens[i]);
-            if (keys[i + 1] <= keys[i] || keys[i + 1] - keys[i] < span)
-                return 0;
-        }
-    }
+    if (!is_prefix_free(keys, klens, m, sentinel))
+        return 0;
     double d[65] = {0};
     double kraft = 0;
     int present[64], np = 0;

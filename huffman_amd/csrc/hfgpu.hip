@@ -101,6 +101,8 @@ struct hf_model {
     uint2 *d_enc2 = nullptr;     // 256 x {code, len} ({0, ENC_LONG_FLAG | len} above 32 bits)
     uint8_t *d_len8 = nullptr;   // 256 x len
     uint16_t *d_lut = nullptr;
+    uint32_t *d_pair = nullptr;  // two-symbol table (only when pair_entries != 0)
+    uint32_t pair_entries = 0;
     uint64_t *d_keys = nullptr;
     uint8_t *d_ksyms = nullptr;
     uint8_t *d_klens = nullptr;
@@ -113,7 +115,8 @@ struct hf_model {
     bool enc_spec = false; // a merged group can exceed 32 bits
     bool has_encode = false;
     bool lut_escapes = false; // the decode table holds entries with the escape bit
-    bool regular_chunks = false; // 64 symbols are expected to differ by < 8 bits in length
+    double mean_bits = 8.0; // code length of a symbol drawn with probability 2^-len
+    bool regular_chunks = false; // 64-symbol chunks sit on few LDS banks unless the image is padded
     uint32_t dec_spec_k = 0; // 16, 8, 7 or 6: codes per 64-bit window the decoder may assume (else 0)
     hipStream_t use_stream = nullptr; // the tables were uploaded on this stream ...
     hipEvent_t ready = nullptr;       // ... and are complete once this event has passed
@@ -240,7 +243,14 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     const size_t off_keys = align_up(off_lut + lut.pool.size() * 2, 16);
     const size_t off_ksyms = off_keys + 256 * sizeof(uint64_t);
     const size_t off_klens = off_ksyms + 256;
-    const size_t total = off_klens + 256;
+    // two-symbol decode table: only for prefix-free models in which nearly every
+    // first-level index holds two complete codes (strongly skewed streams)
+    std::vector<uint32_t> pair;
+    const bool prefix_free = hf::is_prefix_free(keys, klens, m, lut.sentinel);
+    if (prefix_free && lut.w1 >= 6 && hf::build_pair_lut(lut, &pair) > 0.01)
+        pair.clear();
+    const size_t off_pair = align_up(off_klens + 256, 16);
+    const size_t total = off_pair + pair.size() * sizeof(uint32_t);
     hf_ctx::Pinned &ps = ctx->pinned[ctx->pinned_next++ % 4];
     if (ps.used)
         HF_HIP(ctx, hipEventSynchronize(ps.done)); // the copy that last read this buffer is over
@@ -265,6 +275,8 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     std::memcpy(blob + off_keys, keys, m * sizeof(uint64_t));
     std::memcpy(blob + off_ksyms, syms, m);
     std::memcpy(blob + off_klens, klens, m);
+    if (!pair.empty())
+        std::memcpy(blob + off_pair, pair.data(), pair.size() * sizeof(uint32_t));
     for (size_t i = 0; i < ctx->blob_cache.size(); ++i) {
         if (ctx->blob_cache[i].bytes >= total) {
             // kernels of the block's previous owner may still be running: on
@@ -294,6 +306,8 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     mod->d_keys = reinterpret_cast<uint64_t *>(b + off_keys);
     mod->d_ksyms = b + off_ksyms;
     mod->d_klens = b + off_klens;
+    mod->d_pair = pair.empty() ? nullptr : reinterpret_cast<uint32_t *>(b + off_pair);
+    mod->pair_entries = (uint32_t)pair.size();
     mod->lut_entries = (uint32_t)lut.pool.size();
     mod->m = (uint32_t)m;
     mod->sentinel = lut.sentinel;
@@ -308,7 +322,8 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     }
     if (kraft > 0) {
         m1 /= kraft, m2 /= kraft;
-        mod->regular_chunks = 64.0 * (m2 - m1 * m1) < 64.0; // standard deviation below 8 bits
+        mod->mean_bits = m1;
+        mod->regular_chunks = hf::prefer_padded_image(64.0 * m1, std::sqrt(64.0 * std::max(0.0, m2 - m1 * m1)));
     }
     mod->dec_spec_k = hf::pick_decode_window(keys, klens, m, lut.sentinel);
     return HF_OK;
@@ -1051,21 +1066,46 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
     const bool short_k = k < 5 && model->dec_spec_k <= k;
     const bool reg128 = chunk_syms == 128 && !model->lut_escapes && !short_k;
     const bool reg256 = chunk_syms == 256 && !model->lut_escapes && !short_k;
+    // two symbols per lookup: the model has a pair table and a window holds >= 6 codes
+    const uint32_t kk = std::max(k, model->dec_spec_k);
+    const bool pairs = chunk_syms == 64 && model->pair_entries != 0 && kk >= 6 &&
+                       !(ctx->debug & 128);
+    bool swz = model->regular_chunks;
+    if (ctx->debug & 64) // timing experiments: the other image layout
+        swz = !swz;
     if ((chunk_syms == 64 || reg128 || reg256) && !(ctx->debug & 256)) {
-        // register-output kernel: one LDS image serves as input, then as output
-        const uint32_t in_raw = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
-        const uint32_t in_words = in_raw + in_raw / 32 + 1; // padded slots, see SwzWords
-        const uint32_t out_words = HF_SEG_CHUNKS * (chunk_syms / 4 + 1);
-        p.istg_words = std::max(in_words, out_words);
+        // register-output kernel: LDS holds the tables and the segment's span of
+        // the stream only (the output leaves through registers).  The image is
+        // sized for the density of this stream -- the larger of what the model's
+        // code lengths imply and what the buffer actually holds, plus a quarter
+        // -- and never above 8 bits per symbol + slack; a segment that needs
+        // more reads from global memory instead (slower, same result).
+        const uint32_t worst = HF_SEG_CHUNKS * chunk_syms / 4 + 16;
+        const double actual_bits = n_out ? 8.0 * (double)in_bytes / (double)n_out : 8.0;
+        const double bits = std::min(8.0, std::max(model->mean_bits, actual_bits) * 1.25 + 0.25);
+        uint32_t cap = (uint32_t)(bits * HF_SEG_CHUNKS * chunk_syms / 32.0) + 64;
+        cap = std::min(worst, (cap + 3u) & ~3u);
+        p.img_cap = cap;
+        p.istg_words = cap + cap / 32 + 4; // padded slots, see SwzWords
         lds = lut_bytes + (size_t)(p.istg_words + 4) * 4;
-        if (reg256) // 64 output registers per lane, two work-groups per CU
-            kern = model->regular_chunks
+        if (pairs) {
+            p.pair = model->d_pair;
+            p.pair_entries = model->pair_entries;
+            lds += (size_t)model->pair_entries * 4;
+            kern = kk >= 16 ? (swz ? dec_kernel_reg<64, 16, true, true, true, true>
+                                   : dec_kernel_reg<64, 16, true, false, true, true>)
+                            : (kk >= 8 ? (swz ? dec_kernel_reg<64, 8, true, true, true, true>
+                                              : dec_kernel_reg<64, 8, true, false, true, true>)
+                                       : (swz ? dec_kernel_reg<64, 6, true, true, true, true>
+                                              : dec_kernel_reg<64, 6, true, false, true, true>));
+        } else if (reg256) // 64 output registers per lane, two work-groups per CU
+            kern = swz
                        ? (k >= 6 ? dec_kernel_reg<256, 6, false, true, false>
                                  : dec_kernel_reg<256, 5, false, true, false>)
                        : (k >= 6 ? dec_kernel_reg<256, 6, false, false, false>
                                  : dec_kernel_reg<256, 5, false, false, false>);
         else if (reg128)
-            kern = model->regular_chunks
+            kern = swz
                        ? (k >= 6 ? dec_kernel_reg<128, 6, false, true, false>
                                  : dec_kernel_reg<128, 5, false, true, false>)
                        : (k >= 6 ? dec_kernel_reg<128, 6, false, false, false>
@@ -1087,7 +1127,7 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
                           : (k == 3 ? dec_kernel_reg<64, 3, true, false, false>
                                     : (k == 2 ? dec_kernel_reg<64, 2, true, false, false>
                                               : dec_kernel_reg<64, 1, true, false, false>));
-        else if (model->regular_chunks)
+        else if (swz)
             kern = k >= 8 ? dec_kernel_reg<64, 8, false, true, false>
                           : (k >= 6 ? dec_kernel_reg<64, 6, false, true, false>
                                     : dec_kernel_reg<64, 5, false, true, false>);

@@ -52,6 +52,32 @@ uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t
                             uint32_t sentinel);
 int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *klens, uint64_t m,
                      uint64_t sentinel, DecodeLut *lut);
+// True when no code of the table is a prefix of another one (keys ascending,
+// left-aligned codes): a code that lies completely inside a bit window then
+// decodes the same whatever follows it.
+bool is_prefix_free(const uint64_t *keys, const uint8_t *klens, uint64_t m, uint32_t sentinel);
+// Two-symbol decode table over the first-level index of `lut` (prefix-free
+// models only).  Entry of index x: sym0 | sym1 << 8 | (len0 + len1) << 16 when
+// the two codes that start at the top of x both end inside its w1 bits.
+// Otherwise HF_PAIR_SLOW is set: with sym0 | len0 << 16 when only the first
+// code ends inside the index (the decoder looks the second one up on its own),
+// with HF_PAIR_UNRESOLVED when the first level cannot resolve the first code
+// either.  Returns the fraction of the index space that is slow -- under a
+// well-compressed stream, where every index is about equally likely, the
+// probability that a lookup needs the fix-up.
+#define HF_PAIR_SLOW 0x80000000u
+#define HF_PAIR_UNRESOLVED 0x40000000u
+double build_pair_lut(const DecodeLut &lut, std::vector<uint32_t> *pair);
+// Layout of the decoder's LDS image of the stream.  Lane l of a wave starts
+// reading near word l * mean_bits / 32 (chunk l of the segment), and 32 lanes
+// are served per LDS cycle, one word per bank (word index mod 32): chunk sizes
+// that are close to a multiple of a power of two put many lanes on one bank.
+// The padded image leaves one slot unused after every 32 words, which moves
+// those lanes apart but costs two instructions per word read.  Returns true
+// when a simulation of the start positions (random walk with the chunk
+// length's mean and standard deviation, fixed seed) expects clearly fewer
+// serialised accesses with the padding.
+bool prefer_padded_image(double mean_bits, double sd_bits);
 
 } // namespace hf
 #endif

@@ -11,6 +11,7 @@
 
 #include "hfgpu.h"
 #include "dev_common.hpp"
+#include "hfgpu_internal.h"
 
 namespace {
 
@@ -49,7 +50,10 @@ struct DecParams {
     const uint8_t *ksyms;
     const uint8_t *klens;
     uint32_t m;
-    uint32_t istg_words;
+    const uint32_t *pair;  // two-symbol table over the first-level index (PAIR kernels), or null
+    uint32_t pair_entries; // 1 << w1 when pair is set
+    uint32_t istg_words;   // LDS words reserved for the stream image (padding slots included)
+    uint32_t img_cap;      // dec_kernel_reg: stream words the image holds
     uint32_t in_aligned16;
     uint32_t out_aligned16;
     uint64_t *trace; // HF_DEC_TRACE builds: 16 stamps per segment, or null
@@ -346,6 +350,28 @@ __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uin
     return 0;
 }
 
+// Completes a two-symbol table entry that is marked slow: the first symbol
+// comes from the entry, or from a single lookup (escapes included) when the
+// entry could not hold it; the second always from a single lookup behind it.
+// Returns the entry the table could not hold: sym0 | sym1 << 8 | (len0 + len1) << 16.
+__device__ inline uint32_t dec_pair_slow(uint64_t win, uint32_t e, const uint16_t *s_lut,
+                                         const DecParams &p, bool &bad)
+{
+    const uint32_t shift = 32 - p.w1;
+    uint32_t sym0 = e & 0xffu, l0 = (e >> 16) & 63u;
+    if (e & HF_PAIR_UNRESOLVED) {
+        uint32_t e0 = s_lut[(uint32_t)(win >> 32) >> shift];
+        if (e0 & 0x8000u)
+            e0 = dec_escape_window(win, e0, s_lut, p, bad);
+        sym0 = e0 & 0xffu, l0 = e0 >> 8;
+    }
+    win <<= (l0 & 63u);
+    uint32_t e1 = s_lut[(uint32_t)(win >> 32) >> shift];
+    if (e1 & 0x8000u)
+        e1 = dec_escape_window(win, e1, s_lut, p, bad);
+    return sym0 | ((e1 & 0xffu) << 8) | ((l0 + (e1 >> 8)) << 16);
+}
+
 // Register-output form of the decode kernel for 64-symbol chunks.  ESC = the
 // model's table has escape entries (codes longer than the first-level index).
 // A lane keeps its CS decoded bytes in CS/4 registers (the symbol loop is
@@ -371,15 +397,24 @@ __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uin
     do {                                                                                      \
     } while (0)
 #endif
-template <int CS, int K, bool ESC, bool SWZ, bool SPEC>
+// PAIR = strongly skewed prefix-free models (short codes dominate): a second
+// table over the same first-level index holds, for almost every index, the TWO
+// symbols whose codes start there and their combined length, so one lookup,
+// one shift and one byte permute serve two symbols; the few indices whose
+// second code does not end inside the index are marked and resolved by two
+// single lookups.  Every iteration still yields exactly two symbols, so the
+// output registers keep their static indices.
+template <int CS, int K, bool ESC, bool SWZ, bool SPEC, bool PAIR = false>
 __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
 {
+    static_assert(!PAIR || (K % 2 == 0 && SPEC && CS == 64), "pair decoding: even K, checked windows");
     extern __shared__ __align__(16) uint8_t smem[];
-    constexpr uint32_t OROW = CS / 4 + 1; // +1: lanes start on different banks
     using Img = typename std::conditional<SWZ, SwzWords, LdsWords>::type;
     const uint32_t lut_bytes = (p.lut_entries * 2u + 15u) & ~15u;
+    const uint32_t pair_bytes = PAIR ? p.pair_entries * 4u : 0u;
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
-    uint32_t *img = reinterpret_cast<uint32_t *>(smem + lut_bytes); // input, then output
+    const uint32_t *s_pair = reinterpret_cast<const uint32_t *>(smem + lut_bytes);
+    uint32_t *img = reinterpret_cast<uint32_t *>(smem + lut_bytes + pair_bytes); // stream image
     uint32_t *s_wave = img + p.istg_words;
 
     const uint64_t seg = blockIdx.x;
@@ -397,7 +432,18 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     const bool valid = c < p.n_chunks;
     const uint32_t cb = valid ? p.chunk_bits[c] : 0u;
     const uint4 *lut16 = reinterpret_cast<const uint4 *>(p.lut);
-    const uint4 lut0 = threadIdx.x < lut_bytes / 16 ? lut16[threadIdx.x] : make_uint4(0, 0, 0, 0);
+    const uint32_t lut_units = lut_bytes / 16, pair_units = pair_bytes / 16;
+    // two units of the table per lane are requested here, unconditionally (what
+    // lies beyond 8 KiB of table follows in a loop below); the pair table likewise
+    const uint4 lut0 = lut16[min(threadIdx.x, lut_units - 1u)];
+    const uint4 lut1 = lut16[min(threadIdx.x + DEC_THREADS, lut_units - 1u)];
+    const uint4 *pair16 = reinterpret_cast<const uint4 *>(PAIR ? (const void *)p.pair : (const void *)p.lut);
+    const uint32_t pair_top = PAIR ? pair_units - 1u : 0u;
+    uint4 pr0 = make_uint4(0, 0, 0, 0), pr1 = pr0;
+    if (PAIR) {
+        pr0 = pair16[min(threadIdx.x, pair_top)];
+        pr1 = pair16[min(threadIdx.x + DEC_THREADS, pair_top)];
+    }
     // (straight-line on purpose: a load behind a branch is waited for at once)
     const uint64_t last_seg = (p.n_chunks - 1) / HF_SEG_CHUNKS;
     const uint64_t so0 = p.seg_off[seg], so1 = p.seg_off[min(seg + 1, last_seg)];
@@ -405,7 +451,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     const uint64_t seg_start = so0 - p.bit_base;
     const uint64_t ubase = seg_start >> 7;
     const uint32_t s_lo = (uint32_t)(seg_start & 127u);
-    constexpr uint32_t IMG_CAP = HF_SEG_CHUNKS * CS / 4 + 16; // words
+    const uint32_t IMG_CAP = p.img_cap; // words; sized by the host for the stream's density
     constexpr int EARLY = 4;                                  // 16-byte units per lane
     const uint64_t whole = p.in_bytes >> 4;
     const uint4 *in16 = reinterpret_cast<const uint4 *>(p.in);
@@ -427,10 +473,21 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     __builtin_amdgcn_sched_barrier(0); // loads return in order: the small ones were issued first
     {
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        if (threadIdx.x < lut_bytes / 16)
+        if (threadIdx.x < lut_units)
             dst[threadIdx.x] = lut0;
-        for (uint32_t i = threadIdx.x + DEC_THREADS; i < lut_bytes / 16; i += DEC_THREADS)
+        if (threadIdx.x + DEC_THREADS < lut_units)
+            dst[threadIdx.x + DEC_THREADS] = lut1;
+        for (uint32_t i = threadIdx.x + 2 * DEC_THREADS; i < lut_units; i += DEC_THREADS)
             dst[i] = lut16[i];
+        if (PAIR) {
+            uint4 *pdst = reinterpret_cast<uint4 *>(smem + lut_bytes);
+            if (threadIdx.x < pair_units)
+                pdst[threadIdx.x] = pr0;
+            if (threadIdx.x + DEC_THREADS < pair_units)
+                pdst[threadIdx.x + DEC_THREADS] = pr1;
+            for (uint32_t i = threadIdx.x + 2 * DEC_THREADS; i < pair_units; i += DEC_THREADS)
+                pdst[i] = pair16[i];
+        }
     }
     uint32_t total;
     const uint32_t excl = block_excl_scan256(cb, s_wave, total);
@@ -484,6 +541,9 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     const uint32_t cnt = valid ? (uint32_t)min((uint64_t)CS, p.n_out - sym0) : 0u;
     const bool fast = use_lds && cnt == (uint32_t)CS;
     uint32_t outw[CS / 4];
+#pragma unroll
+    for (int i = 0; i < CS / 4; ++i)
+        outw[i] = 0; // (lanes without a whole chunk still take part in the exchange below)
     bool bad = false;
     bool dirty = false; // SPEC: some group of K codes ran past its 64-bit window
     if (fast && K >= 8 && !ESC && !SPEC) {
@@ -502,6 +562,41 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                 pack |= dec_symbol<Img, false>(br, s_lut, shift, p, bad) << (8 * k);
             }
             outw[i] = pack;
+        }
+    } else if (fast && PAIR) {
+        // as below, two symbols per lookup
+        uint32_t pos = s_lo + excl;
+        const uint32_t shift = 32 - p.w1;
+#pragma unroll
+        for (int i = 0; i < CS / 4; ++i)
+            outw[i] = 0;
+#pragma unroll
+        for (int g = 0; g < CS; g += K) {
+            const Img src{img};
+            const uint32_t wi = pos >> 5;
+            const uint32_t w0 = src(wi), w1 = src(wi + 1), w2 = src(wi + 2);
+            const uint32_t sh = 32u - (pos & 31u); // 1..32
+            const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
+            const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
+            uint64_t win = ((uint64_t)hi << 32) | lo;
+            uint32_t used = 0;
+#pragma unroll
+            for (int k = 0; k < K; k += 2) {
+                const int j = g + k;
+                if (j < CS) {
+                    uint32_t e = s_pair[(uint32_t)(win >> 32) >> shift];
+                    if (__builtin_expect((int32_t)e < 0, 0))
+                        e = dec_pair_slow(win, e, s_lut, p, bad);
+                    const uint32_t len = e >> 16;
+                    win <<= (len & 63u);
+                    used += len;
+                    // bytes j % 4 and j % 4 + 1 of the output word take the entry's low two bytes
+                    const uint32_t sel = (j & 2) ? 0x05040100u : 0x03020504u;
+                    outw[j >> 2] = __builtin_amdgcn_perm(e, outw[j >> 2], sel);
+                }
+            }
+            pos += used;
+            dirty = dirty || used > 64u;
         }
     } else if (fast) {
         // No reader state besides the bit position: every K symbols the lane
@@ -558,42 +653,67 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
     DEC_TRACE(4); // decoded
     if (bad && !dirty) // a dirty lane's symbols (and errors) are not real: it decodes again below
         atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
-    __syncthreads(); // every lane is done with the compressed image: reuse it for the output
-    if (fast) {
-        uint32_t *orow = img + threadIdx.x * OROW;
-#pragma unroll
-        for (int i = 0; i < CS / 4; ++i)
-            orow[i] = outw[i];
-    }
-    DEC_TRACE(5); // output rows written
-    __syncthreads();
-    DEC_TRACE(6);
     if (!use_lds)
-        return;
-    // coalesced copy-out of the whole chunks of the segment
-    const uint64_t obase = seg * HF_SEG_CHUNKS * (uint64_t)CS;
-    const uint64_t oleft = p.n_out - obase;
-    const uint32_t full_chunks = (uint32_t)min(oleft / CS, (uint64_t)HF_SEG_CHUNKS);
-    const uint32_t seg_len = full_chunks * CS;
-    for (uint32_t o = threadIdx.x * 16u; o < seg_len; o += DEC_THREADS * 16u) {
-        const uint32_t ch = o / CS, within = o % CS;
-        const uint32_t *srcw = img + ch * OROW + within / 4;
-        uint4 v;
-        v.x = srcw[0];
-        v.y = srcw[1];
-        v.z = srcw[2];
-        v.w = srcw[3];
-        if (p.out_aligned16) {
-            *reinterpret_cast<uint4 *>(p.out + obase + o) = v;
-        } else {
-            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-            for (uint32_t i = 0; i < 16u; ++i)
-                p.out[obase + o + i] = (uint8_t)(vv[i >> 2] >> (8 * (i & 3)));
+        return; // (uniform over the workgroup)
+    // Output.  A lane holds the CS bytes of its chunk; stored as they are, one
+    // store instruction would touch 64 different lines with 16 bytes each.  The
+    // four lanes of a quad exchange their 16-byte units instead (a 4 x 4
+    // transpose through DPP quad permutes, no LDS and no barrier): afterwards
+    // lane r holds unit r of each of the quad's four chunks, and every store
+    // instruction writes 64 contiguous bytes per quad.
+    const bool whole_chunk = fast && !dirty;
+    if (fast && !p.out_aligned16) {
+        // (buffers at odd addresses: the lane stores its own bytes)
+        if (!dirty) {
+#pragma unroll
+            for (int i = 0; i < CS / 4; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    p.out[sym0 + 4 * i + q] = (uint8_t)(outw[i] >> (8 * q));
+            }
         }
     }
-    DEC_TRACE(7); // copied out
+    const unsigned long long whole_mask = __ballot(whole_chunk && p.out_aligned16);
+    {
+        const uint32_t r = threadIdx.x & 3u;
+        const bool odd1 = (r & 1u) != 0, odd2 = (r & 2u) != 0;
+        const uint32_t quad0 = threadIdx.x & 60u & 63u; // first lane of the quad within the wave
+#pragma unroll
+        for (int blk = 0; blk < CS / 64; ++blk) {
+            uint32_t *U = outw + 16 * blk; // four units of four dwords
+#pragma unroll
+            for (int stage = 0; stage < 2; ++stage) {
+                const bool odd = stage == 0 ? odd1 : odd2;
+                const int step = stage == 0 ? 1 : 2; // partner lane = lane ^ step, partner unit = unit ^ step
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u & step)
+                        continue;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const uint32_t a = U[4 * u + d], c = U[4 * (u + step) + d];
+                        const uint32_t give = odd ? a : c;
+                        const uint32_t recv = (uint32_t)(stage == 0
+                            ? __builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xf, 0xf, false)   // quad_perm [1,0,3,2]
+                            : __builtin_amdgcn_update_dpp(0, (int)give, 0x4E, 0xf, 0xf, false)); // quad_perm [2,3,0,1]
+                        U[4 * u + d] = odd ? recv : a;
+                        U[4 * (u + step) + d] = odd ? c : recv;
+                    }
+                }
+            }
+            // slot i now holds unit (4 blk + r) of the chunk of quad lane i
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if ((whole_mask >> (quad0 + i)) & 1ull) {
+                    const uint64_t ci = c - r + i; // that lane's chunk
+                    uint4 v = make_uint4(U[4 * i + 0], U[4 * i + 1], U[4 * i + 2], U[4 * i + 3]);
+                    *reinterpret_cast<uint4 *>(p.out + ci * CS + (4u * blk + r) * 16u) = v;
+                }
+            }
+        }
+    }
+    DEC_TRACE(7); // stored
     if (SPEC) {
-        __syncthreads(); // the chunk's (wrong) bytes from the image have been stored
         if (dirty) {
             GlobalWords src{p.in, p.in_bytes, ubase * 4};
             BitReader<GlobalWords> br(src, s_lo + excl);

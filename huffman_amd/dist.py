@@ -113,6 +113,8 @@ def gather_histograms(local_hist: torch.Tensor, dist):
     since every rank derives the same codebook from it, row r times the code
     lengths is shard r's bit length (plan_from_histograms)."""
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and local_hist.is_cuda:
+        local_hist = local_hist.cpu()  # gloo gathers host tensors
     every = torch.empty(world * 256, dtype=local_hist.dtype, device=local_hist.device)
     dist.all_gather_into_tensor(every, local_hist.contiguous())
     return every.view(world, 256).cpu().numpy()
