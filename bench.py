@@ -374,6 +374,13 @@ def main():
         sys.stdout.flush()
         json_fd = os.dup(1)
         os.dup2(2, 1)
+        if world == 1 and "RANK" not in os.environ:  # a single rank without a launcher
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                free_port = sk.getsockname()[1]
+            for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"),
+                             ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(free_port))):
+                os.environ.setdefault(key, val)
         if rehearse:
             dist.init_process_group("gloo")
         else:

@@ -140,17 +140,25 @@ __device__ __forceinline__ uint32_t enc_sum_lens(const uint32_t raw[ENC_SPT / 4]
 // Threads that produce the same number of words each (eight for 8-bit codes)
 // would otherwise OR into the same few banks at the same time; irregular
 // streams gain a little as well.
-__device__ __forceinline__ uint32_t enc_slot(uint32_t w) { return w + (w >> 5); }
+// (PAD = false: streams of short, irregular codes -- the kernels that use the
+// carry sink -- keep the plain layout: the slot arithmetic costs them more
+// than the conflicts it avoids.)
+template <bool PAD>
+__device__ __forceinline__ uint32_t enc_slot(uint32_t w) { return PAD ? w + (w >> 5) : w; }
 constexpr int ENC_IMG_SLOTS = ENC_WINW + ENC_WINW / 32 + 4;
 // The slot of image word w as a pointer, in two instructions: left to itself
 // the compiler distributes the scaling over the sum and needs three.
+template <bool PAD>
 __device__ __forceinline__ uint32_t *enc_slot_ptr(uint32_t *stg, uint32_t w)
 {
+    if (!PAD)
+        return stg + w;
     uint32_t byte_off;
     asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(byte_off) : "v"(w), "v"(w >> 5));
     return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(stg) + byte_off);
 }
 
+template <bool PAD>
 __device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos,
                                             uint64_t code, uint32_t len, uint32_t wlo,
                                             uint32_t whi, uint32_t clip)
@@ -166,7 +174,7 @@ __device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos,
         const uint32_t part =
             (uint32_t)(code >> (len - take)) & (take == 32 ? ~0u : ((1u << take) - 1u));
         if (w >= wlo && w < whi)
-            __hip_atomic_fetch_or(stg + enc_slot(w - wlo), part << (32u - o - take), __ATOMIC_RELAXED,
+            __hip_atomic_fetch_or(stg + enc_slot<PAD>(w - wlo), part << (32u - o - take), __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         bitpos += take;
         len -= take;
@@ -176,6 +184,7 @@ __device__ __forceinline__ void enc_or_bits(uint32_t *stg, uint32_t bitpos,
 // Bit sink of one thread: codes are appended MSB-first to a 64-bit accumulator
 // and every completed 32-bit word is ORed into the image.  Only image words
 // [wlo, wlo + ENC_WINW) exist in a pass; others are dropped.
+template <bool PAD>
 struct EncSink {
     uint32_t *stg;
     uint32_t w;   // image word being filled, relative to wlo (wraps below the window)
@@ -188,7 +197,7 @@ struct EncSink {
     __device__ __forceinline__ void emit(uint32_t val)
     {
         if (w < (uint32_t)ENC_WINW)
-            __hip_atomic_fetch_or(stg + enc_slot(w), val, __ATOMIC_RELAXED,
+            __hip_atomic_fetch_or(stg + enc_slot<PAD>(w), val, __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         ++w;
     }
@@ -211,6 +220,7 @@ struct EncSink {
 // The sink of the single-pass fast path: straight-line code in which only the
 // LDS OR itself is predicated (lanes whose word is not complete yet sit the
 // instruction out), and the image slot is computed from a word index.
+template <bool PAD>
 struct EncSinkFlat {
     uint32_t *stg;
     uint32_t w; // image word being filled
@@ -228,14 +238,14 @@ struct EncSinkFlat {
         const bool full = nb >= 32 && alive;
         nb &= 31u;
         if (full)
-            __hip_atomic_fetch_or(enc_slot_ptr(stg, w), (uint32_t)(acc >> nb), __ATOMIC_RELAXED,
+            __hip_atomic_fetch_or(enc_slot_ptr<PAD>(stg, w), (uint32_t)(acc >> nb), __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         w += full ? 1 : 0;
     }
     __device__ __forceinline__ void finish()
     {
         if (nb && alive)
-            __hip_atomic_fetch_or(enc_slot_ptr(stg, w), (uint32_t)(acc << (32 - nb)),
+            __hip_atomic_fetch_or(enc_slot_ptr<PAD>(stg, w), (uint32_t)(acc << (32 - nb)),
                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
@@ -245,6 +255,7 @@ struct EncSinkFlat {
 // supplies len | len << 27, so that one add advances it, wraps it and leaves
 // "word complete" in the carry; the low bits only collect the lengths
 // (at most 32 x 31, far from bit 27).
+template <bool PAD>
 struct EncSinkCarry {
     uint32_t *stg;
     uint32_t w;
@@ -262,7 +273,7 @@ struct EncSinkCarry {
         const bool full = __builtin_add_overflow(nbl, y, &next);
         nbl = next;
         if (full)
-            __hip_atomic_fetch_or(enc_slot_ptr(stg, w), (uint32_t)(acc >> (nbl >> 27)),
+            __hip_atomic_fetch_or(enc_slot_ptr<PAD>(stg, w), (uint32_t)(acc >> (nbl >> 27)),
                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         w += full ? 1 : 0;
     }
@@ -270,7 +281,7 @@ struct EncSinkCarry {
     {
         const uint32_t nb = nbl >> 27;
         if (nb)
-            __hip_atomic_fetch_or(enc_slot_ptr(stg, w), (uint32_t)(acc << (32 - nb)),
+            __hip_atomic_fetch_or(enc_slot_ptr<PAD>(stg, w), (uint32_t)(acc << (32 - nb)),
                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
@@ -278,6 +289,7 @@ struct EncSinkCarry {
 // Generic form: walks the thread's run again through the 64-bit table with a
 // rolled loop.  Used when a code is longer than a packed entry holds and when
 // a tile needs more than one image pass (both rare).
+template <bool PAD>
 __device__ inline void enc_pack_thread_rolled(const EncParams &p, uint64_t sym0,
                                                     uint32_t vcnt, uint32_t *stg, uint32_t bitpos,
                                                     uint32_t nbits, uint32_t wlo)
@@ -286,7 +298,7 @@ __device__ inline void enc_pack_thread_rolled(const EncParams &p, uint64_t sym0,
         return;
     if (((bitpos + nbits - 1) >> 5) < wlo || (bitpos >> 5) >= wlo + ENC_WINW)
         return;
-    EncSink sink(stg, bitpos, wlo);
+    EncSink<PAD> sink(stg, bitpos, wlo);
     for (uint32_t k = 0; k < vcnt; ++k) {
         const uint64_t e = p.tab[p.in[sym0 + k]];
         const uint32_t len = (uint32_t)e & 63u;
@@ -324,7 +336,7 @@ __device__ __forceinline__ uint32_t enc_pick(const uint32_t (&raw)[ENC_BATCH][EN
     return v;
 }
 
-template <int G, bool SPEC, bool FULL, bool CARRY>
+template <int G, bool SPEC, bool FULL, bool CARRY, bool PAD>
 __device__ __forceinline__ bool enc_pack_thread(const uint32_t (&raw)[ENC_BATCH][ENC_SPT / 4],
                                                 uint32_t t, uint32_t vcnt, const uint2 *s_tab2,
                                                 uint32_t *stg, uint32_t bitpos)
@@ -332,7 +344,7 @@ __device__ __forceinline__ bool enc_pack_thread(const uint32_t (&raw)[ENC_BATCH]
     static_assert(!(CARRY && SPEC), "the carry sink needs groups of at most 31 bits");
     constexpr int LG = 4; // lookups per group = the four symbols of one input dword
     const uint2 *tab = s_tab2 + (threadIdx.x & (ENC_REPL - 1));
-    std::conditional_t<CARRY, EncSinkCarry, EncSinkFlat> sink(stg, bitpos);
+    std::conditional_t<CARRY, EncSinkCarry<PAD>, EncSinkFlat<PAD>> sink(stg, bitpos);
     uint2 cur[LG], nxt[LG];
     auto fetch = [&](uint2 e[LG], int q) {
         const uint32_t dw = enc_pick(raw, t, q); // the four symbols of this group
@@ -635,6 +647,7 @@ __device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, 
 // Second half of an image pass: complete the tile's last word from the
 // symbols that follow it (last pass only) and copy the pass's words out with
 // coalesced byte-swapped 16-byte stores, clearing the image on the way.
+template <bool PAD>
 __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *stg,
                                                 uint32_t la_bits, uint32_t la_have,
                                                 uint64_t E, uint64_t gbase,
@@ -647,7 +660,7 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
     // the word that holds the tile's last bit is completed by the first `need`
     // bits of what follows the tile
     if (threadIdx.x == 0 && last_pass && need)
-        __hip_atomic_fetch_or(stg + enc_slot((endbit >> 5) - wlo), la_bits >> (32u - need),
+        __hip_atomic_fetch_or(stg + enc_slot<PAD>((endbit >> 5) - wlo), la_bits >> (32u - need),
                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     // the stream ends inside this tile's last word when fewer than `need`
@@ -665,9 +678,16 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
         // the thread that copies a unit out also clears it: the image is all
         // zero again when the pass ends, without a separate sweep
         // (the unit's four words share a 32-word row, so their slots are adjacent)
-        uint32_t *src = stg + enc_slot(j);
-        const uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
-        src[0] = 0, src[1] = 0, src[2] = 0, src[3] = 0;
+        uint32_t *src = stg + enc_slot<PAD>(j);
+        uint4 v;
+        if (PAD) {
+            v = make_uint4(src[0], src[1], src[2], src[3]);
+            src[0] = 0, src[1] = 0, src[2] = 0, src[3] = 0;
+        } else { // j is a multiple of four and the image is 16-byte aligned
+            uint4 *src4 = reinterpret_cast<uint4 *>(__builtin_assume_aligned(src, 16));
+            v = *src4;
+            *src4 = make_uint4(0, 0, 0, 0);
+        }
         const uint32_t vals[4] = {bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)};
         const uint64_t b = u << 4;
         if ((u << 2) >= ga && (u << 2) + 4 <= gb && b + 16 <= limit && b + 16 <= p.out_cap &&
@@ -745,6 +765,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
     const uint64_t trace_t0 = wall_clock64();
     uint64_t *trp = nullptr;
 #endif
+    constexpr bool PAD = !CARRY; // image layout, see enc_slot
     const bool CHAINED = p.desc != nullptr; // else: tile offsets come from the scan kernel
     __shared__ __align__(16) uint32_t stg2[2][ENC_IMG_SLOTS];
     __shared__ uint2 s_tab[256 * ENC_REPL];
@@ -949,17 +970,17 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
                 // common case, straight-line: the whole tile fits one image pass
                 if (my_bits && !(p.debug & 2u)) {
                     const bool done =
-                        enc_pack_thread<G, SPEC, FULL, CARRY>(raw, 0, vc, s_tab, stg, s_lo + toff);
+                        enc_pack_thread<G, SPEC, FULL, CARRY, PAD>(raw, 0, vc, s_tab, stg, s_lo + toff);
                     if (SPEC && __builtin_expect(!done, 0)) // rare by the host's choice of G
-                        enc_pack_thread_rolled(p, base + t0, vc, stg, s_lo + toff, my_bits, 0);
+                        enc_pack_thread_rolled<PAD>(p, base + t0, vc, stg, s_lo + toff, my_bits, 0);
                 }
                 ENC_TRACE_TILE(t, 0); // packed
-                enc_finish_pass(p, stg, s_la[t], s_have[t], E, gbase, g0, g1, endbit, need, nwords,
+                enc_finish_pass<PAD>(p, stg, s_la[t], s_have[t], E, gbase, g0, g1, endbit, need, nwords,
                                 0, false);
             } else {
                 for (uint32_t wlo = 0; wlo < nwords; wlo += ENC_WINW) {
-                    enc_pack_thread_rolled(p, base + t0, vc, stg, s_lo + toff, my_bits, wlo);
-                    enc_finish_pass(p, stg, s_la[t], s_have[t], E, gbase, g0, g1, endbit, need,
+                    enc_pack_thread_rolled<PAD>(p, base + t0, vc, stg, s_lo + toff, my_bits, wlo);
+                    enc_finish_pass<PAD>(p, stg, s_la[t], s_have[t], E, gbase, g0, g1, endbit, need,
                                     nwords, wlo, true);
                 }
             }
