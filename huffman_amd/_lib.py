@@ -88,6 +88,10 @@ SIGNATURES = {
                                    C.c_uint32, u16p, u64p, u64p]),
     "hf_decode_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                  C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hf_decode_range_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                       C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hf_decode_window_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                        C.c_uint64, C.c_int, C.c_void_p, u64p, u64p]),
     "hf_encoder_write_value_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p,
                                               u64p, u64p]),
 }

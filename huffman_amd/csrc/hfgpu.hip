@@ -1198,25 +1198,31 @@ int hf_decode_serial(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, ui
     return flags_to_status(ctx, res[HF_RES_FLAGS]);
 }
 
-int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
-                       uint64_t n_out, uint32_t chunk_syms, uint16_t *d_chunk_bits,
-                       uint64_t *d_seg_off)
+} // extern "C"
+
+namespace {
+
+// hf_build_gap_array, and the same for a window of a longer stream.
+//   first_start  bit of d_in[0] at which the first code starts (0..255)
+//   bit_base     stream bit of bit 0 of d_in[0]: the segment offsets are absolute
+//   whole        the window reaches the end of the stream: n_want symbols are
+//                expected (HF_ERR_DECODE if it holds fewer).  Otherwise the
+//                codes that start in the window's last 2048 bits are left for
+//                the next window (they may run past its end), and as many
+//                whole segments as the rest holds, at most n_want symbols,
+//                are laid out; *n_done receives that count (possibly 0).
+//   *end_bit     bit (from bit 0 of d_in[0]) behind the last of those symbols
+int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
+              uint32_t first_start, uint64_t bit_base, bool whole, uint64_t n_want,
+              uint32_t chunk_syms, uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint64_t *n_done,
+              uint64_t *end_bit)
 {
-    DeviceGuard on(ctx);
-    if (!ctx)
-        return HF_ERR_BAD_ARG;
-    if (!valid_chunk_syms(chunk_syms))
-        return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: chunk_syms must be 64, 128 or 256");
-    if (n_out && (!d_chunk_bits || !d_seg_off))
-        return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: null output");
     GapParams g{};
     // d.out is not written; any non-null value passes the shared argument checks
-    int rc = fill_dec_params(ctx, model, d_in, in_bytes, 0, n_out,
+    int rc = fill_dec_params(ctx, model, d_in, in_bytes, 0, n_want,
                              reinterpret_cast<uint8_t *>(d_chunk_bits), ctx->d_result, &g.d);
     if (rc != HF_OK)
         return rc;
-    if (n_out == 0)
-        return HF_OK;
     if (in_bytes == 0 || in_bytes >= (1ull << 58))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: empty or oversized stream");
     g.d.chunk_syms = chunk_syms;
@@ -1224,9 +1230,11 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
     g.total_bits = in_bytes * 8;
     g.n_sub = (g.total_bits + GAP_SUB_BITS - 1) / GAP_SUB_BITS;
     g.n_wg = (g.n_sub + GAP_THREADS - 1) / GAP_THREADS;
-    g.n_chunks = (n_out + chunk_syms - 1) / chunk_syms;
+    g.n_chunks = (n_want + chunk_syms - 1) / chunk_syms; // (upper bound until n_out is known)
     g.chunk_bits = d_chunk_bits;
     g.seg_off = d_seg_off;
+    g.first_start = first_start;
+    g.bit_base = bit_base;
     if (g.n_wg >= (1ull << 31))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: stream too long");
 
@@ -1281,11 +1289,42 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
     uint64_t total_syms = 0;
     HF_HIP(ctx, hipMemcpyAsync(&total_syms, g.wg_base + g.n_wg, 8, hipMemcpyDeviceToHost,
                                ctx->stream));
-    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (total_syms < n_out)
-        return fail(ctx, HF_ERR_DECODE,
-                    "hf_build_gap_array: the stream holds %llu symbols, fewer than n_out = %llu",
-                    (unsigned long long)total_syms, (unsigned long long)n_out);
+    uint64_t n_out = n_want;
+    if (whole) {
+        HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (total_syms < n_want)
+            return fail(ctx, HF_ERR_DECODE,
+                        "hf_build_gap_array: the stream holds %llu symbols, fewer than n_out = %llu",
+                        (unsigned long long)total_syms, (unsigned long long)n_want);
+    } else {
+        // symbols whose code starts before the window's last two sub-sequences
+        uint64_t safe = 0;
+        if (g.total_bits >= 4 * (uint64_t)GAP_SUB_BITS) {
+            const uint64_t j_lim = g.total_bits / GAP_SUB_BITS - 2; // first sub-sequence left out
+            const uint64_t wg = j_lim / GAP_THREADS;
+            uint32_t cnt[GAP_THREADS];
+            const uint64_t first_sub = wg * GAP_THREADS, n_cnt = j_lim - first_sub;
+            HF_HIP(ctx, hipMemcpyAsync(&safe, g.wg_base + wg, 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (n_cnt)
+                HF_HIP(ctx, hipMemcpyAsync(cnt, g.cnt + first_sub, n_cnt * 4, hipMemcpyDeviceToHost,
+                                           ctx->stream));
+            HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint64_t i = 0; i < n_cnt; ++i)
+                safe += cnt[i];
+        } else {
+            HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        const uint64_t seg_syms = (uint64_t)HF_SEG_CHUNKS * chunk_syms;
+        n_out = std::min(n_want, safe) / seg_syms * seg_syms;
+    }
+    *n_done = n_out;
+    *end_bit = first_start;
+    if (n_out == 0) {
+        ctx->scratch_busy = false;
+        return HF_OK;
+    }
+    g.d.n_out = n_out;
+    g.n_chunks = (n_out + chunk_syms - 1) / chunk_syms;
     hipLaunchKernelGGL(gap_emit_kernel, wgs, dim3(GAP_THREADS), lds, ctx->stream, g);
     hipLaunchKernelGGL(gap_diff_kernel, dim3((uint32_t)((g.n_chunks + GAP_THREADS - 1) / GAP_THREADS)),
                        dim3(GAP_THREADS), 0, ctx->stream, g);
@@ -1294,7 +1333,32 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
     HF_HIP(ctx, hipMemcpyAsync(res, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->scratch_busy = false;
+    *end_bit = res[HF_RES_END_BIT];
     return flags_to_status(ctx, res[HF_RES_FLAGS]);
+}
+
+} // namespace
+
+extern "C" {
+
+int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
+                       uint64_t n_out, uint32_t chunk_syms, uint16_t *d_chunk_bits,
+                       uint64_t *d_seg_off)
+{
+    DeviceGuard on(ctx);
+    if (!ctx)
+        return HF_ERR_BAD_ARG;
+    if (!valid_chunk_syms(chunk_syms))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: chunk_syms must be 64, 128 or 256");
+    if (n_out && (!d_chunk_bits || !d_seg_off))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: null output");
+    if (n_out == 0) {
+        DecParams unused{};
+        return fill_dec_params(ctx, model, d_in, in_bytes, 0, 0, nullptr, ctx->d_result, &unused);
+    }
+    uint64_t n_done = 0, end_bit = 0;
+    return gap_build(ctx, model, d_in, in_bytes, 0, 0, true, n_out, chunk_syms, d_chunk_bits,
+                     d_seg_off, &n_done, &end_bit);
 }
 
 // ------------------------------------------------------- host-buffer forms
@@ -1719,6 +1783,99 @@ int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
     if (n_out)
         HF_HIP(ctx, hipMemcpyAsync(h_out, a + off_out, n_out, hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HF_OK;
+}
+
+int hf_decode_range_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_win,
+                         uint64_t win_bytes, uint64_t bit_base, uint64_t n_out, uint32_t chunk_syms,
+                         const uint16_t *h_chunk_bits, const uint64_t *h_seg_off, uint8_t *h_out)
+{
+    DeviceGuard on(ctx);
+    if (!ctx || !model || (!h_win && win_bytes) || (!h_out && n_out))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_range_host: null pointer");
+    if (n_out == 0)
+        return HF_OK;
+    if (!h_chunk_bits || !h_seg_off)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_range_host: gap arrays missing");
+    uint64_t n_chunks = 0, n_segs = 0;
+    if (hf_gap_layout(n_out, chunk_syms, &n_chunks, &n_segs) != HF_OK)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_range_host: chunk_syms must be 64, 128 or 256");
+    if (bit_base & 31u)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_range_host: bit_base must be a multiple of 32");
+    const size_t off_out = align_up(win_bytes + 16, 256);
+    const size_t off_cb = align_up(off_out + n_out + 16, 256);
+    const size_t off_so = align_up(off_cb + n_chunks * 2 + 16, 256);
+    int rc = ensure_arena(ctx, off_so + n_segs * 8 + 16);
+    if (rc != HF_OK)
+        return rc;
+    uint8_t *a = static_cast<uint8_t *>(ctx->arena);
+    if (win_bytes)
+        HF_HIP(ctx, hipMemcpyAsync(a, h_win, win_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HF_HIP(ctx, hipMemcpyAsync(a + off_cb, h_chunk_bits, n_chunks * 2, hipMemcpyHostToDevice,
+                               ctx->stream));
+    HF_HIP(ctx, hipMemcpyAsync(a + off_so, h_seg_off, n_segs * 8, hipMemcpyHostToDevice,
+                               ctx->stream));
+    rc = hf_decode(ctx, model, a, win_bytes, bit_base, n_out, chunk_syms,
+                   reinterpret_cast<const uint16_t *>(a + off_cb),
+                   reinterpret_cast<const uint64_t *>(a + off_so), a + off_out);
+    if (rc != HF_OK)
+        return rc;
+    HF_HIP(ctx, hipMemcpyAsync(h_out, a + off_out, n_out, hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HF_OK;
+}
+
+int hf_decode_window_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_win,
+                          uint64_t win_bytes, uint32_t start_bit, uint64_t n_max, int last,
+                          uint8_t *h_out, uint64_t *n_decoded, uint64_t *end_bit)
+{
+    DeviceGuard on(ctx);
+    if (!ctx || !model || !n_decoded || !end_bit || (!h_win && win_bytes) || (!h_out && n_max))
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_window_host: null pointer");
+    if (start_bit > 255)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_window_host: start_bit must be below 256");
+    *n_decoded = 0;
+    *end_bit = start_bit;
+    if (n_max == 0)
+        return HF_OK;
+    const uint32_t cs = 64;
+    uint64_t n_chunks = 0, n_segs = 0;
+    hf_gap_layout(n_max, cs, &n_chunks, &n_segs);
+    const size_t off_out = align_up(win_bytes + 16, 256);
+    const size_t off_cb = align_up(off_out + n_max + 16, 256);
+    const size_t off_so = align_up(off_cb + n_chunks * 2 + 16, 256);
+    int rc = ensure_arena(ctx, off_so + n_segs * 8 + 16);
+    if (rc != HF_OK)
+        return rc;
+    uint8_t *a = static_cast<uint8_t *>(ctx->arena);
+    if (win_bytes)
+        HF_HIP(ctx, hipMemcpyAsync(a, h_win, win_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint16_t *d_cb = reinterpret_cast<uint16_t *>(a + off_cb);
+    uint64_t *d_so = reinterpret_cast<uint64_t *>(a + off_so);
+    uint64_t n = 0, end = start_bit;
+    rc = win_bytes ? gap_build(ctx, model, a, win_bytes, start_bit, 0, last != 0, n_max, cs, d_cb,
+                               d_so, &n, &end)
+                   : HF_ERR_DECODE;
+    if (rc == HF_ERR_DECODE && last && n_max <= HF_WRITE_VALUE_MAX && start_bit == 0) {
+        // the stream ends early: it is continued with zero bits, as the reference's
+        // drain loop does (src/huffman/decode/mod.rs:219-229) -- the sequential walk
+        rc = hf_decode_serial(ctx, model, a, win_bytes, 0, n_max, a + off_out);
+        if (rc != HF_OK)
+            return rc;
+        n = n_max;
+        end = win_bytes * 8;
+    } else if (rc != HF_OK) {
+        return rc;
+    } else if (n) {
+        rc = hf_decode(ctx, model, a, win_bytes, 0, n, cs, d_cb, d_so, a + off_out);
+        if (rc != HF_OK)
+            return rc;
+    }
+    if (n)
+        HF_HIP(ctx, hipMemcpyAsync(h_out, a + off_out, n, hipMemcpyDeviceToHost, ctx->stream));
+    HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_decoded = n;
+    *end_bit = end;
     return HF_OK;
 }
 

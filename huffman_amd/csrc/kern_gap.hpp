@@ -60,6 +60,8 @@ struct GapParams {
     uint32_t *start32;   // [n_chunks + 1] low 32 bits of the chunk start bits
     uint64_t n_chunks;
     uint32_t first;      // first launch: no earlier results to reuse
+    uint32_t first_start; // bit of the stream's first sub-sequence at which its first code starts
+    uint64_t bit_base;   // stream bit of bit 0 of d.in (added to the segment offsets)
     uint32_t per_window; // symbols decoded per 64-bit window: per_window * sentinel <= 64
     uint16_t *chunk_bits;
     uint64_t *seg_off;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_snapshot_kernel(GapParams g)
     const uint64_t w = (uint64_t)blockIdx.x * GAP_THREADS + threadIdx.x;
     if (w >= g.n_wg)
         return;
-    const uint32_t v = w ? g.exit_off[w * GAP_THREADS - 1] : 0u;
+    const uint32_t v = w ? g.exit_off[w * GAP_THREADS - 1] : g.first_start;
     g.wg_in[w] = v;
     if (v != g.wg_used[w])
         atomicOr(g.changed, 1u);
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_emit_kernel(GapParams g)
                 const uint64_t c = s / cs;
                 g.start32[c] = (uint32_t)(bit0 + pos);
                 if ((c % HF_SEG_CHUNKS) == 0)
-                    g.seg_off[c / HF_SEG_CHUNKS] = bit0 + pos;
+                    g.seg_off[c / HF_SEG_CHUNKS] = g.bit_base + bit0 + pos;
                 until = cs;
             }
             const uint32_t e = gap_entry(win, s_lut, g.d, bad);
@@ -294,8 +296,10 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_emit_kernel(GapParams g)
             pos += len;
             ++s;
             --until;
-            if (s == g.d.n_out)
+            if (s == g.d.n_out) {
                 g.start32[g.n_chunks] = (uint32_t)(bit0 + pos); // end of the last chunk
+                g.d.result[HF_RES_END_BIT] = bit0 + pos;        // (counted from bit 0 of d.in)
+            }
         }
     }
     if (bad)

@@ -53,7 +53,7 @@ typedef struct hf_ctx hf_ctx;     /* one GPU + stream + scratch */
 typedef struct hf_model hf_model; /* device-resident codebook + decode tables */
 
 /* Device-side result block written by the *_async calls (4 x uint64_t). */
-enum { HF_RES_TOTAL_BITS = 0, HF_RES_FLAGS = 1, HF_RES_WORDS = 4 };
+enum { HF_RES_TOTAL_BITS = 0, HF_RES_FLAGS = 1, HF_RES_END_BIT = 2, HF_RES_WORDS = 4 };
 enum {
     HF_FLAG_CAPACITY = 1u,  /* an output store was suppressed: buffer too small */
     HF_FLAG_DECODE = 2u,    /* window below the smallest key */
@@ -312,6 +312,33 @@ HF_API int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_i
                           uint64_t in_bytes, uint64_t n_out, uint32_t chunk_syms,
                           const uint16_t *h_chunk_bits, const uint64_t *h_seg_off,
                           uint8_t *h_out);
+/* Decoder::read (src/huffman/decode/mod.rs:70-137) for a reader that is drained
+ * piece by piece, so that the host never holds more than a window of the
+ * stream and a piece of the output.
+ *
+ * hf_decode_range_host: a range of whole segments of a stream whose gap array
+ * is at hand.  h_win holds the stream from bit `bit_base` (a multiple of 32;
+ * bit 0 of h_win[0]) at least up to the end of the range plus 16 bytes of
+ * run-ahead (or to the stream's end); h_chunk_bits / h_seg_off start at the
+ * range's first chunk / segment, seg_off values stay absolute.
+ *
+ * hf_decode_window_host: the same without a gap array (a file the reference
+ * wrote): the window's first code starts at bit `start_bit` of h_win[0].  With
+ * last == 0 the device lays out and decodes as many whole segments of 64 x
+ * HF_SEG_CHUNKS symbols as lie safely inside the window (codes that start in
+ * its last 2048 bits are left for the next window), at most n_max symbols;
+ * with last != 0 the window reaches the stream's end and exactly n_max symbols
+ * are decoded (a stream that ends early is continued with zero bits as in
+ * :219-229, for up to HF_WRITE_VALUE_MAX symbols).  *n_decoded symbols land in
+ * h_out; *end_bit is the bit of the window, counted from bit 0 of h_win[0], at
+ * which the next symbol starts. */
+HF_API int hf_decode_range_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_win,
+                                uint64_t win_bytes, uint64_t bit_base, uint64_t n_out,
+                                uint32_t chunk_syms, const uint16_t *h_chunk_bits,
+                                const uint64_t *h_seg_off, uint8_t *h_out);
+HF_API int hf_decode_window_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_win,
+                                 uint64_t win_bytes, uint32_t start_bit, uint64_t n_max, int last,
+                                 uint8_t *h_out, uint64_t *n_decoded, uint64_t *end_bit);
 HF_API int hf_encoder_write_value_host(hf_ctx *ctx, const uint8_t *h_in, uint64_t n,
                                        const uint64_t codes[256], const uint64_t lens[256],
                                        uint64_t state[3], uint64_t *ret);

@@ -88,22 +88,37 @@ struct Model {
 
 namespace stats {
 
-// generate_histogram (src/stats.rs:13-28): the reader is drained in BUF-sized
-// reads; the counting itself runs on the GPU.
+// generate_histogram (src/stats.rs:13-28): the reader is drained into a piece
+// of PIECE bytes at a time; every piece is counted on the GPU and the 256
+// counts are summed, so the host holds one piece whatever the input's size.
+constexpr std::size_t HISTOGRAM_PIECE = std::size_t(64) << 20;
 template <class Reader>
 std::array<usize, 256> generate_histogram(Reader &reader)
 {
-    std::vector<u8> all;
-    std::vector<u8> buffer(BUF);
-    while (true) {
-        const std::size_t n = reader.read(buffer.data(), buffer.size());
-        if (n == 0)
-            break;
-        all.insert(all.end(), buffer.begin(), buffer.begin() + n);
-    }
+    std::vector<u8> piece;
     std::array<usize, 256> hist{};
-    Runtime::check(hf_histogram_host(Runtime::ctx(), all.data(), all.size(), hist.data()),
-                   "generate_histogram");
+    bool end = false;
+    while (!end) {
+        // (grown as the reader delivers: a small input never allocates a whole piece)
+        std::size_t have = 0;
+        while (have < HISTOGRAM_PIECE) {
+            if (piece.size() < have + BUF)
+                piece.resize(std::min(HISTOGRAM_PIECE, std::max(piece.size() * 2, have + BUF)));
+            const std::size_t n = reader.read(piece.data() + have, piece.size() - have);
+            if (n == 0) {
+                end = true;
+                break;
+            }
+            have += n;
+        }
+        if (have == 0)
+            break;
+        std::array<usize, 256> part{};
+        Runtime::check(hf_histogram_host(Runtime::ctx(), piece.data(), have, part.data()),
+                       "generate_histogram");
+        for (int i = 0; i < 256; ++i)
+            hist[i] += part[i];
+    }
     return hist;
 }
 
@@ -284,6 +299,44 @@ struct GapArray {
     std::vector<std::uint16_t> chunk_bits;
     std::vector<usize> seg_off;
     usize symbols = 0; // symbols covered
+
+    // Bit length of the stream the arrays describe.
+    usize total_bits() const
+    {
+        if (seg_off.empty())
+            return 0;
+        usize bits = seg_off.back();
+        for (std::size_t c = (seg_off.size() - 1) * HF_SEG_CHUNKS; c < chunk_bits.size(); ++c)
+            bits += chunk_bits[c];
+        return bits;
+    }
+    // Side metadata is only trusted when it is consistent in itself and fits
+    // the stream it is used for: right symbol count and array sizes, the first
+    // segment at bit 0, every segment offset equal to its predecessor plus the
+    // chunk lengths in between and, when the stream's size is known, the last
+    // bit inside the stream's last byte.  Anything else (a stale or foreign
+    // side file) is ignored and the gap array is rebuilt from the stream.
+    bool fits(usize readbytes, std::optional<usize> stream_bytes) const
+    {
+        usize nc = 0, ns = 0;
+        if (symbols != readbytes || hf_gap_layout(readbytes, chunk_syms, &nc, &ns) != HF_OK)
+            return false;
+        if (chunk_bits.size() != nc || seg_off.size() != ns)
+            return false;
+        if (ns == 0)
+            return true;
+        if (seg_off[0] != 0)
+            return false;
+        usize run = 0;
+        for (usize sg = 0; sg < ns; ++sg) {
+            if (seg_off[sg] != run)
+                return false;
+            const usize c1 = std::min<usize>(nc, (sg + 1) * HF_SEG_CHUNKS);
+            for (usize c = sg * HF_SEG_CHUNKS; c < c1; ++c)
+                run += chunk_bits[c];
+        }
+        return !stream_bytes || (run + 7) / 8 == *stream_bytes;
+    }
 };
 
 // -------------------------------------------------- src/huffman/encode.rs
@@ -293,21 +346,61 @@ namespace encode {
 // calculate_length (src/huffman/encode.rs:140-149)
 inline usize calculate_length(usize val) { return hf_calculate_length(val); }
 
+// The byte-emission bookkeeping of Encoder::write (src/huffman/encode.rs:57-116)
+// without the bytes: how many bytes `put` (:57-66) and `cleanup` (:67-83) hand
+// to the inner writer while the symbols of one call pass, and what the call
+// returns (:115).  Pure counter arithmetic on {buffer, remaining_bits,
+// writeout}; the stream itself is produced on the GPU.  hf_encoder_write_value
+// replays the same schedule on the device and is what the tests hold this
+// against.
+struct WriteSchedule {
+    usize buffer = 0, remaining_bits = 64, writeout = 0; // encode.rs:43-47
+    // Returns the value Encoder::write returns for these symbols.
+    usize advance(const u8 *buf, std::size_t n, const std::array<usize, 256> &codes,
+                  const std::array<usize, 256> &lens)
+    {
+        usize emitted = 0;
+        for (std::size_t i = 0; i < n; ++i) {
+            const usize code = codes[buf[i]], len = lens[buf[i]];
+            if (len > 64)
+                throw IoError(true, "Codelen > 64"); // encode.rs:102-104
+            while (len > remaining_bits) { // put: one byte out
+                emitted += 1;
+                buffer <<= 8;
+                remaining_bits += 8;
+            }
+            remaining_bits -= len;
+            buffer += code << (remaining_bits & 63);
+            if (buffer & 0x0000000000FF0000ull) { // cleanup: five bytes out
+                emitted += 5;
+                buffer <<= 40;
+                remaining_bits += 40;
+            }
+        }
+        writeout += emitted;
+        const usize tz = buffer ? (usize)__builtin_ctzll(buffer) : 64;
+        return emitted + 8 - tz / 8;
+    }
+};
+
 // struct Encoder<'a, W: Write, M: Model> (src/huffman/encode.rs:26-34).
 // write() stages the input; the GPU encodes when `flush()` is called (or when
 // STAGE_LIMIT bytes are pending): the reference's progressive inner writes
 // are not observable in the final stream.  The return value of write() and
 // `writeout` between calls follow the reference's put/cleanup schedule
-// exactly while `track_write_value` is set and calls carry at most
-// HF_WRITE_VALUE_MAX symbols (a device lane replays the automaton, one small
-// launch per call).  Otherwise write() returns the bytes it really handed to
-// `inner` during the call (0 while staging) and `writeout` is exact again
-// after flush().  Callers that ignore the return value, like the file
-// compressor below, clear the flag.
+// exactly while `track_write_value` is set (WriteSchedule: counters only, on
+// the host, no device round trip per call).  Otherwise write() returns the
+// bytes it really handed to `inner` during the call (0 while staging) and
+// `writeout` is exact again after flush().  Callers that ignore the return
+// value, like the file compressor below, clear the flag and save the pass
+// over the symbols.
 template <class W>
 class Encoder {
   public:
-    static constexpr std::size_t STAGE_LIMIT = std::size_t(1) << 30;
+    // bytes staged before the device encodes them: a file larger than this is
+    // compressed piece by piece (pieces are whole segments, so the gap arrays
+    // concatenate and only a shared boundary byte is carried over)
+    static constexpr std::size_t STAGE_LIMIT = std::size_t(256) << 20;
 
     W inner;
     const Model *model;
@@ -326,20 +419,16 @@ class Encoder {
     {
         ensure_device_model();
         usize ret = 0;
-        const bool replay = track_write_value && n <= HF_WRITE_VALUE_MAX;
+        const bool replay = track_write_value;
         if (replay) {
-            usize state[3] = {auto_buffer_, auto_remaining_, auto_writeout_};
-            Runtime::check(hf_encoder_write_value_host(Runtime::ctx(), buf, n, dm_->codes().data(),
-                                                       dm_->lens().data(), state, &ret),
-                           "Encoder::write");
-            auto_buffer_ = state[0];
-            auto_remaining_ = state[1];
-            auto_writeout_ = state[2];
-            writeout = auto_writeout_;
-        } else {
-            track_write_value = false;
+            ret = schedule_.advance(buf, n, dm_->codes(), dm_->lens());
+            writeout = schedule_.writeout;
         }
         readbytes += n;
+        // (one reservation instead of doubling: a growing vector would hold two
+        // copies of the staged bytes at the moment it moves them)
+        if (pending_.size() + n > (std::size_t(1) << 20) && pending_.capacity() < STAGE_LIMIT + n)
+            pending_.reserve(STAGE_LIMIT + std::max<std::size_t>(n, BUF));
         pending_.insert(pending_.end(), buf, buf + n);
         const usize before = emitted_;
         if (pending_.size() >= STAGE_LIMIT)
@@ -389,14 +478,16 @@ class Encoder {
         const usize n = final ? pending_.size() : pending_.size() - pending_.size() % seg_syms;
         if (n == 0 && !final)
             return;
-        std::vector<u8> out(hf_encode_bound(dm_->handle(), n, lead) + 8);
+        // (not value-initialised: only the bytes the stream really has are touched)
+        const std::size_t out_cap = hf_encode_bound(dm_->handle(), n, lead) + 8;
+        std::unique_ptr<u8[]> out(new u8[out_cap]);
         usize nch = 0, nsg = 0;
         hf_gap_layout(n, gap_.chunk_syms, &nch, &nsg);
         std::vector<std::uint16_t> cb(nch);
         std::vector<usize> so(nsg);
         usize bits = 0;
         Runtime::check(hf_encode_host(Runtime::ctx(), dm_->handle(), pending_.data(), n, lead,
-                                      out.data(), out.size(), gap_.chunk_syms,
+                                      out.get(), out_cap, gap_.chunk_syms,
                                       n ? cb.data() : nullptr, n ? so.data() : nullptr, &bits),
                        "Encoder::flush");
         // gap array: segment offsets become absolute; batches are only cut at
@@ -418,7 +509,7 @@ class Encoder {
         } else if (final) {
             fillbits = (u8)((8 - total_bits_ % 8) % 8);
         }
-        write_all(out.data(), nbytes);
+        write_all(out.get(), nbytes);
         emitted_ += nbytes;
         if (!track_write_value || final)
             writeout = (total_bits_ + 7) / 8;
@@ -430,7 +521,7 @@ class Encoder {
     GapArray gap_;
     usize total_bits_ = 0, emitted_ = 0;
     u8 carry_ = 0;
-    usize auto_buffer_ = 0, auto_remaining_ = 64, auto_writeout_ = 0; // encode.rs:43-47
+    WriteSchedule schedule_;
 };
 
 } // namespace encode
@@ -498,6 +589,8 @@ struct Header {
         h.magic.assign(p + off, p + off + ml);
         off += ml;
         const usize cnt = le64();
+        if (cnt > (n - off) / 10) // an entry is 10 bytes: a count beyond the buffer is garbage
+            throw Panic(HF_ERR_BAD_ARG, "header: table length exceeds the header");
         for (usize i = 0; i < cnt; ++i) {
             const usize key = le64();
             if (off + 2 > n)
@@ -557,7 +650,7 @@ inline std::vector<u8> read(const u8 *data, std::size_t n, const Model &model, u
 {
     DeviceModel dm(model);
     std::vector<u8> out(goalsbyte);
-    const bool use_gap = gap && gap->symbols >= goalsbyte && goalsbyte > 0;
+    const bool use_gap = gap && goalsbyte > 0 && gap->fits(goalsbyte, n);
     Runtime::check(hf_decode_host(Runtime::ctx(), dm.handle(), data, n, goalsbyte,
                                   use_gap ? gap->chunk_syms : 64,
                                   use_gap ? gap->chunk_bits.data() : nullptr,
@@ -571,74 +664,160 @@ inline std::vector<u8> read(const std::vector<u8> &data, const Model &model, usi
     return read(data.data(), data.size(), model, goalsbyte, gap);
 }
 
-// struct Decoder<R: Read> (decode/mod.rs:15-26): streaming decoder.  The
-// first read() drains the inner reader and decodes the whole stream on the
-// GPU; later calls are served from that buffer, so any read size (the
-// reference's example uses 15 bytes) costs a memcpy.
+// struct Decoder<R: Read> (decode/mod.rs:15-26): streaming decoder.  read()
+// hands out decoded bytes piece by piece: the inner reader is drained only as
+// far as the next piece needs, the GPU decodes that piece, and any read size
+// (the reference's example uses 15 bytes) is a memcpy out of it.  The host
+// holds a window of the stream and one piece of output, whatever the stream's
+// size.  With the encoder's gap array (checked with GapArray::fits first) a
+// piece is a run of whole segments; without one -- a file the reference wrote
+// -- the device finds the code boundaries of each window itself.
 template <class R>
 class Decoder {
   public:
+    static constexpr usize PIECE_SYMS = usize(64) << 20;    // with a gap array: symbols per piece
+    static constexpr std::size_t WINDOW_BYTES = std::size_t(32) << 20; // without: stream bytes per window
+
     // Decoder::new (decode/mod.rs:29-47)
     template <class W>
     Decoder(R reader, encode::Encoder<W> &encoder)
         : inner_(std::move(reader)), goalsbyte_(encoder.readbytes),
           dm_(std::make_unique<DeviceModel>(*encoder.model)), gap_(encoder.gap())
     {
+        use_gap_ = goalsbyte_ > 0 && gap_.fits(goalsbyte_, std::nullopt);
     }
-    // Decoder::from_header (decode/mod.rs:48-66)
-    Decoder(const header::Header &header, R reader, const GapArray *gap = nullptr)
+    // Decoder::from_header (decode/mod.rs:48-66); stream_bytes = length of the
+    // stream behind the reader when the caller knows it (a file)
+    Decoder(const header::Header &header, R reader, const GapArray *gap = nullptr,
+            std::optional<usize> stream_bytes = std::nullopt)
         : inner_(std::move(reader)), goalsbyte_(header.readbytes),
           dm_(std::make_unique<DeviceModel>(header.btree, header.sentinel))
     {
-        if (gap)
+        if (gap && goalsbyte_ > 0 && gap->fits(goalsbyte_, stream_bytes)) {
             gap_ = *gap;
+            use_gap_ = true;
+        }
     }
+    bool uses_gap_array() const { return use_gap_; }
     // impl Read::read (decode/mod.rs:70-137)
     std::size_t read(u8 *buf, std::size_t len)
     {
-        if (!decoded_)
-            decode_all();
-        const std::size_t k = std::min<std::size_t>(len, out_.size() - writeout_);
-        std::memcpy(buf, out_.data() + writeout_, k);
-        writeout_ += k;
-        return k;
+        std::size_t done = 0;
+        while (done < len) {
+            if (pos_ == out_.size() && !next_piece())
+                break;
+            const std::size_t k = std::min<std::size_t>(len - done, out_.size() - pos_);
+            std::memcpy(buf + done, out_.data() + pos_, k);
+            pos_ += k;
+            done += k;
+        }
+        return done;
     }
     std::size_t read_to_end(std::vector<u8> &dst)
     {
-        if (!decoded_)
-            decode_all();
-        const std::size_t k = out_.size() - writeout_;
-        dst.insert(dst.end(), out_.begin() + writeout_, out_.end());
-        writeout_ = out_.size();
-        return k;
+        std::size_t total = 0;
+        while (pos_ < out_.size() || next_piece()) {
+            dst.insert(dst.end(), out_.begin() + (std::ptrdiff_t)pos_, out_.end());
+            total += out_.size() - pos_;
+            pos_ = out_.size();
+        }
+        return total;
     }
 
   private:
-    void decode_all()
+    // Reads from the inner reader until the window reaches stream byte `upto`
+    // (exclusive) or the reader ends.
+    void fill_to(usize upto)
     {
-        std::vector<u8> comp, chunk(1 << 16);
-        while (true) {
-            const std::size_t n = inner_.read(chunk.data(), chunk.size());
+        while (!eof_ && comp_base_ + comp_.size() < upto) {
+            const std::size_t have = comp_.size();
+            const std::size_t want = (std::size_t)std::min<usize>(upto - comp_base_ - have, 1u << 22);
+            comp_.resize(have + want);
+            const std::size_t n = inner_.read(comp_.data() + have, want);
+            comp_.resize(have + n);
             if (n == 0)
-                break;
-            comp.insert(comp.end(), chunk.begin(), chunk.begin() + n);
+                eof_ = true;
         }
-        out_.resize(goalsbyte_);
-        const bool use_gap = gap_.symbols >= goalsbyte_ && goalsbyte_ > 0;
-        Runtime::check(hf_decode_host(Runtime::ctx(), dm_->handle(), comp.data(), comp.size(),
-                                      goalsbyte_, gap_.chunk_syms,
-                                      use_gap ? gap_.chunk_bits.data() : nullptr,
-                                      use_gap ? gap_.seg_off.data() : nullptr, out_.data()),
-                       "Decoder::read");
-        decoded_ = true;
     }
+    void drop_before(usize byte)
+    {
+        if (byte > comp_base_) {
+            const std::size_t k = (std::size_t)std::min<usize>(byte - comp_base_, comp_.size());
+            comp_.erase(comp_.begin(), comp_.begin() + (std::ptrdiff_t)k);
+            comp_base_ += k;
+        }
+    }
+    bool next_piece()
+    {
+        out_.clear();
+        pos_ = 0;
+        if (next_sym_ >= goalsbyte_)
+            return false;
+        return use_gap_ ? piece_with_gap() : piece_from_window();
+    }
+    bool piece_with_gap()
+    {
+        const usize seg_syms = (usize)HF_SEG_CHUNKS * gap_.chunk_syms;
+        const usize s0 = next_sym_ / seg_syms, n_segs = gap_.seg_off.size();
+        const usize s1 = std::min<usize>(n_segs, s0 + std::max<usize>(1, PIECE_SYMS / seg_syms));
+        const usize n_piece = std::min(goalsbyte_, s1 * seg_syms) - next_sym_;
+        const usize end_bit = s1 < n_segs ? gap_.seg_off[s1] : gap_.total_bits();
+        const usize first_byte = (gap_.seg_off[s0] / 8) & ~usize(15);
+        drop_before(first_byte);
+        fill_to((end_bit + 7) / 8 + 16);
+        if (comp_base_ != first_byte || comp_base_ + comp_.size() < (end_bit + 7) / 8)
+            throw Panic(HF_ERR_DECODE, "Decoder::read: the stream ends before the gap array does");
+        out_.resize(n_piece);
+        Runtime::check(hf_decode_range_host(Runtime::ctx(), dm_->handle(), comp_.data(), comp_.size(),
+                                            first_byte * 8, n_piece, gap_.chunk_syms,
+                                            gap_.chunk_bits.data() + s0 * HF_SEG_CHUNKS,
+                                            gap_.seg_off.data() + s0, out_.data()),
+                       "Decoder::read");
+        next_sym_ += n_piece;
+        return true;
+    }
+    bool piece_from_window()
+    {
+        std::size_t window = WINDOW_BYTES;
+        while (true) {
+            fill_to(comp_base_ + window);
+            const bool last = eof_;
+            // a code has at least one bit: the window cannot hold more symbols than bits
+            const usize n_max = std::min<usize>({goalsbyte_ - next_sym_, (usize)comp_.size() * 8 + 8,
+                                                 usize(256) << 20});
+            const bool all = last && n_max == goalsbyte_ - next_sym_;
+            out_.resize(n_max);
+            usize n = 0, end_bit = 0;
+            Runtime::check(hf_decode_window_host(Runtime::ctx(), dm_->handle(), comp_.data(),
+                                                 comp_.size(), start_bit_, n_max, all ? 1 : 0,
+                                                 out_.data(), &n, &end_bit),
+                           "Decoder::read");
+            if (n == 0 && !all) {
+                if (last) // the window is the rest of the stream and more symbols than fit a piece remain
+                    throw Panic(HF_ERR_DECODE, "Decoder::read: window without a whole segment");
+                window *= 2; // very long codes: not one whole segment inside the window yet
+                continue;
+            }
+            out_.resize(n);
+            next_sym_ += n;
+            start_bit_ = (std::uint32_t)(end_bit % 8);
+            drop_before(comp_base_ + end_bit / 8);
+            return n != 0;
+        }
+    }
+
     R inner_;
     usize goalsbyte_;
     std::unique_ptr<DeviceModel> dm_;
     GapArray gap_;
-    std::vector<u8> out_;
-    std::size_t writeout_ = 0;
-    bool decoded_ = false;
+    bool use_gap_ = false;
+    std::vector<u8> comp_; // window of the stream, from stream byte comp_base_
+    usize comp_base_ = 0;
+    bool eof_ = false;
+    usize next_sym_ = 0;          // first symbol of the next piece
+    std::uint32_t start_bit_ = 0; // without a gap array: bit of comp_[0] at which it starts
+    std::vector<u8> out_;         // the current piece
+    std::size_t pos_ = 0;
 };
 
 // vault::Decoder (decode/vault.rs:28-39,65-86): the reference's experimental
@@ -771,15 +950,23 @@ inline void write_gap_sidecar(const std::string &path, const huffman::GapArray &
 }
 inline bool read_gap_sidecar(const std::string &path, huffman::GapArray &g)
 {
-    std::ifstream f(path, std::ios::binary);
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f)
+        return false;
+    const std::uint64_t size = (std::uint64_t)f.tellg();
+    f.seekg(0);
     char tag[8];
     std::uint64_t nc = 0, ns = 0;
-    if (!f || !f.read(tag, 8) || std::memcmp(tag, "hfgap1", 6) != 0)
+    if (size < 36 || !f.read(tag, 8) || std::memcmp(tag, "hfgap1", 6) != 0)
         return false;
     f.read(reinterpret_cast<char *>(&g.chunk_syms), 4);
     f.read(reinterpret_cast<char *>(&g.symbols), 8);
     f.read(reinterpret_cast<char *>(&nc), 8);
     f.read(reinterpret_cast<char *>(&ns), 8);
+    // the counts must account for the file exactly: nothing is allocated for a
+    // truncated or foreign file
+    if (!f || nc > size / 2 || ns > size / 8 || 36 + nc * 2 + ns * 8 != size)
+        return false;
     g.chunk_bits.resize(nc);
     g.seg_off.resize(ns);
     f.read(reinterpret_cast<char *>(g.chunk_bits.data()), (std::streamsize)(nc * 2));
@@ -799,7 +986,8 @@ inline void stream_compress_with_header_information(const std::string &source,
         // bytes written are the same as on the general path below.
         std::ifstream sz(source, std::ios::binary | std::ios::ate);
         const std::uint64_t size = sz ? (std::uint64_t)sz.tellg() : 0;
-        if (size > 0 && size <= huffman::encode::Encoder<FileWriter>::STAGE_LIMIT) {
+        constexpr std::uint64_t SINGLE_UPLOAD_LIMIT = std::uint64_t(1) << 30;
+        if (size > 0 && size <= SINGLE_UPLOAD_LIMIT) {
             std::vector<u8> data(size);
             if (reader.read(data.data(), size) != size)
                 throw IoError(false, "failed to read the source file");
@@ -865,22 +1053,36 @@ inline void stream_compress_with_header_information(const std::string &source,
 inline void stream_decompress_with_header_information(const std::string &source,
                                                       const std::string &destination)
 {
+    std::uint64_t file_size = 0;
+    {
+        std::ifstream sz(source, std::ios::binary | std::ios::ate);
+        if (sz)
+            file_size = (std::uint64_t)sz.tellg();
+    }
     FileReader reader(source);
     u8 fixed[12];
     if (reader.read(fixed, 12) != 12 || std::memcmp(fixed, "pzhf", 4) != 0)
         throw Panic(HF_ERR_BAD_ARG, "not a pzhf file");
     const std::uint64_t hlen = bytes_to_u64(fixed + 4);
+    if (hlen > file_size - 12) // (nothing is allocated for a length the file cannot hold)
+        throw Panic(HF_ERR_BAD_ARG, "header length exceeds the file");
     std::vector<u8> hb(hlen);
     if (reader.read(hb.data(), hlen) != hlen)
         throw Panic(HF_ERR_BAD_ARG, "truncated header");
     const auto hd = huffman::header::Header::from_binary(hb);
     huffman::GapArray gap;
     const bool have_gap = read_gap_sidecar(gap_sidecar_path(source), gap);
-    huffman::decode::Decoder<FileReader> dec(hd, std::move(reader), have_gap ? &gap : nullptr);
+    // the side file is used only if it fits this very stream (GapArray::fits)
+    huffman::decode::Decoder<FileReader> dec(hd, std::move(reader), have_gap ? &gap : nullptr,
+                                             file_size - 12 - hlen);
     FileWriter out(destination);
-    std::vector<u8> all;
-    dec.read_to_end(all);
-    out.write(all.data(), all.size());
+    std::vector<u8> piece(std::size_t(16) << 20);
+    while (true) {
+        const std::size_t n = dec.read(piece.data(), piece.size());
+        if (n == 0)
+            break;
+        out.write(piece.data(), n);
+    }
     out.flush();
 }
 

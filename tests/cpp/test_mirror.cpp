@@ -60,10 +60,12 @@ int main()
         CHECK((u64_to_bytes(23534134) == std::array<u8, 8>{0, 0, 0, 0, 1, 103, 26, 54}));
         CHECK((u64_to_bytes(3234159383273ull) == std::array<u8, 8>{0, 0, 2, 241, 2, 235, 210, 233}));
         CHECK((u64_to_bytes(534457654) == std::array<u8, 8>{0, 0, 0, 0, 31, 219, 45, 54}));
+        CHECK((u64_to_bytes(8273839836383ull) == std::array<u8, 8>{0, 0, 7, 134, 103, 72, 204, 223}));
     });
     // src/lib.rs:133-141 test_u64_to_bytes_roundtrip
     run("test_u64_to_bytes_roundtrip", [] {
-        for (std::uint64_t v : {341ull, 1ull, 32425ull, 23534134ull, 3234159383273ull, 534457654ull})
+        for (std::uint64_t v : {341ull, 1ull, 32425ull, 23534134ull, 3234159383273ull, 534457654ull,
+                                8273839836383ull})
             CHECK(bytes_to_u64(u64_to_bytes(v).data()) == v);
     });
     // src/stats.rs:49-60 testing_histogram
@@ -94,6 +96,9 @@ int main()
         std::vector<usize> c = {99, 99, 99, 1, 1, 1};
         huffman::calculate_codeword_length_inplace(c);
         CHECK((c == std::vector<usize>{2, 2, 2, 3, 4, 4}));
+        std::vector<usize> d = {8, 7, 6, 5, 4, 3};
+        huffman::calculate_codeword_length_inplace(d);
+        CHECK((d == std::vector<usize>{2, 2, 3, 3, 3, 3}));
     });
     // src/huffman/encode.rs:179-186 binary_length
     run("binary_length", [] {
@@ -306,6 +311,74 @@ int main()
         std::remove(gap_sidecar_path(dst).c_str());
         std::remove(back.c_str());
         rmdir(dir);
+    });
+    // Encoder::write's return value and `writeout` (encode.rs:91-116) are kept by
+    // counters on the host; the device replay of the same schedule must agree
+    // call by call, whatever the call sizes
+    run("write_schedule_matches_device_replay", [] {
+        auto data = stats::generate_random_byte_vector(0, 60, 200000, [] {
+            std::vector<u8> w(60);
+            for (int i = 0; i < 60; ++i)
+                w[i] = (u8)(1 + 250 / (i + 1));
+            return w;
+        }(), 3);
+        Huffman h = Huffman::from_slice(data);
+        Encoder<VecWriter> enc(VecWriter{}, h);
+        usize state[3] = {0, 64, 0};
+        std::size_t off = 0, call = 0;
+        const std::size_t sizes[] = {1, 7, 4096, 15, 65536, 3, 4096, 100000};
+        while (off < data.size()) {
+            const std::size_t n = std::min(sizes[call++ % 8], data.size() - off);
+            const usize got = enc.write(data.data() + off, n);
+            usize want = 0;
+            Runtime::check(hf_encoder_write_value_host(Runtime::ctx(), data.data() + off, n,
+                                                       h.codewords().data(), h.length().data(),
+                                                       state, &want),
+                           "device replay");
+            CHECK(got == want);
+            CHECK(enc.writeout == state[2]);
+            off += n;
+        }
+        enc.flush();
+        CHECK(enc.writeout == enc.inner.get_ref().size());
+    });
+    // a gap array is only used when it fits the stream; a Decoder fed pieces
+    run("gap_array_validation", [] {
+        auto data = stats::generate_random_byte_vector(0, 30, 100000, std::vector<u8>(30, 3), 5);
+        for (std::size_t i = 0; i < data.size(); i += 2)
+            data[i] = 1;
+        Huffman h = Huffman::from_slice(data);
+        Encoder<VecWriter> enc(VecWriter{}, h);
+        enc.write(data);
+        enc.flush();
+        const auto &stream = enc.inner.get_ref();
+        huffman::GapArray g = enc.gap();
+        CHECK(g.fits(data.size(), stream.size()) && g.fits(data.size(), std::nullopt));
+        CHECK(!g.fits(data.size() - 1, stream.size()) && !g.fits(data.size(), stream.size() + 1));
+        huffman::GapArray bad = g;
+        bad.chunk_bits[5] += 1; // no longer adds up to the next segment offset
+        CHECK(!bad.fits(data.size(), std::nullopt));
+        bad = g;
+        bad.seg_off[0] = 8;
+        CHECK(!bad.fits(data.size(), stream.size()));
+        bad = g;
+        bad.chunk_bits.pop_back();
+        CHECK(!bad.fits(data.size(), stream.size()));
+        // decode::read and Decoder ignore what does not fit and still decode correctly
+        bad = g;
+        bad.chunk_bits[7] ^= 3;
+        CHECK(huffman::decode::read(stream, h, data.size(), &bad) == data);
+        auto hd = huffman::header::Header::from(enc);
+        huffman::decode::Decoder<SliceReader> dec(hd, SliceReader(stream), &bad, stream.size());
+        CHECK(!dec.uses_gap_array());
+        std::vector<u8> got;
+        dec.read_to_end(got);
+        CHECK(got == data);
+        huffman::decode::Decoder<SliceReader> dec2(hd, SliceReader(stream), &g, stream.size());
+        CHECK(dec2.uses_gap_array());
+        got.clear();
+        dec2.read_to_end(got);
+        CHECK(got == data);
     });
     // Codelen > 64 is InvalidData (encode.rs:102-104)
     run("codelen_over_64_is_invalid_data", [] {

@@ -293,3 +293,181 @@ def test_encode_host_in_overlapping_pieces(ctx, orc, kind, cs, lead):
     finally:
         L.hf_ctx_set_option(ctx, b"host_piece_mib", 64)
         L.hf_model_destroy(model)
+
+
+# ---- a stream decoded window by window / range by range (what Decoder::read does
+# ---- with a reader it drains piece by piece)
+
+@pytest.mark.parametrize("kind", ["zipf", "geometric", "testfile", "uniform"])
+def test_decode_window_host_walks_a_stream_without_gap_array(ctx, orc, kind):
+    L = _lib.lib()
+    n = 5_000_011
+    data = synth.generate_host(kind, n, seed=77)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    stream, _ = orc.encode_slice(data, codes, lens)
+    model = make_model(ctx, codes, lens)
+    try:
+        window = 1 << 18
+        base, start_bit, done = 0, 0, 0
+        pieces = []
+        calls = 0
+        while done < n:
+            win = stream[base: base + window]
+            last = base + window >= stream.size
+            n_max = min(n - done, win.size * 8 + 8)
+            out = np.zeros(n_max, dtype=np.uint8)
+            got, end = C.c_uint64(), C.c_uint64()
+            whole = last and n_max == n - done
+            rc = L.hf_decode_window_host(ctx, model, win.ctypes.data_as(u8p), win.size, start_bit,
+                                         n_max, 1 if whole else 0, out.ctypes.data_as(u8p),
+                                         C.byref(got), C.byref(end))
+            assert rc == _lib.HF_OK, L.hf_last_error(ctx)
+            calls += 1
+            assert got.value > 0
+            if not whole:
+                assert got.value % (64 * 256) == 0  # whole segments only
+            pieces.append(out[: got.value])
+            done += got.value
+            base += end.value // 8
+            start_bit = end.value % 8
+        assert calls > 2
+        assert np.array_equal(np.concatenate(pieces), data)
+    finally:
+        L.hf_model_destroy(model)
+
+
+@pytest.mark.parametrize("kind,cs", [("zipf", 64), ("geometric", 64), ("uniform", 128)])
+def test_decode_range_host_decodes_runs_of_segments(ctx, orc, kind, cs):
+    L = _lib.lib()
+    n = 3_000_017
+    data = synth.generate_host(kind, n, seed=78)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    want, _ = orc.encode_slice(data, codes, lens)
+    model = make_model(ctx, codes, lens)
+    try:
+        nch, nsg = (n + cs - 1) // cs, ((n + cs - 1) // cs + 255) // 256
+        out = np.zeros(want.size + 64, dtype=np.uint8)
+        cb = np.zeros(nch, dtype=np.uint16)
+        so = np.zeros(nsg, dtype=np.uint64)
+        bits = C.c_uint64()
+        rc = L.hf_encode_host(ctx, model, data.ctypes.data_as(u8p), n, 0, out.ctypes.data_as(u8p),
+                              out.size, cs, cb.ctypes.data_as(u16p), so.ctypes.data_as(u64p),
+                              C.byref(bits))
+        assert rc == _lib.HF_OK
+        stream = out[: want.size]
+        assert np.array_equal(stream, want)
+        seg_syms = 256 * cs
+        per_piece = 7  # segments
+        got = []
+        for s0 in range(0, nsg, per_piece):
+            s1 = min(nsg, s0 + per_piece)
+            n_piece = min(n, s1 * seg_syms) - s0 * seg_syms
+            first_byte = (int(so[s0]) // 8) & ~15
+            end_bit = int(so[s1]) if s1 < nsg else int(bits.value)
+            win = np.ascontiguousarray(stream[first_byte: (end_bit + 7) // 8 + 16])
+            piece = np.zeros(n_piece, dtype=np.uint8)
+            rc = L.hf_decode_range_host(ctx, model, win.ctypes.data_as(u8p), win.size,
+                                        first_byte * 8, n_piece, cs,
+                                        cb[s0 * 256:].ctypes.data_as(u16p),
+                                        so[s0:].ctypes.data_as(u64p), piece.ctypes.data_as(u8p))
+            assert rc == _lib.HF_OK, L.hf_last_error(ctx)
+            got.append(piece)
+        assert np.array_equal(np.concatenate(got), data)
+    finally:
+        L.hf_model_destroy(model)
+
+
+# ---- side files and lengths that cannot be trusted
+
+def test_cli_ignores_side_files_that_do_not_fit_and_rejects_bad_lengths(tmp_path, orc):
+    n = 700_001
+    a = synth.generate_host("zipf", n, seed=31)
+    b = synth.generate_host("testfile", n, seed=32)  # same symbol count, another stream
+    fa, fb = tmp_path / "a.bin", tmp_path / "b.bin"
+    fa.write_bytes(a.tobytes())
+    fb.write_bytes(b.tobytes())
+    ca, cbf, back = tmp_path / "a.pzhf", tmp_path / "b.pzhf", tmp_path / "back.bin"
+    assert run_cli(str(fa), str(ca), "h", "c").returncode == 0
+    assert run_cli(str(fb), str(cbf), "h", "c").returncode == 0
+    side_a, side_b = str(ca) + ".hfgap", str(cbf) + ".hfgap"
+    good = open(side_a, "rb").read()
+    # a foreign side file (same number of symbols, other stream)
+    open(side_a, "wb").write(open(side_b, "rb").read())
+    r = run_cli(str(ca), str(back), "h", "d")
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == a.tobytes()
+    # truncated, and with counts that do not account for the file
+    for bad in (good[: len(good) // 2], good[:20], good[:12] + b"\xff" * 24 + good[36:],
+                good + b"\0\0"):
+        open(side_a, "wb").write(bad)
+        back.unlink()
+        r = run_cli(str(ca), str(back), "h", "d")
+        assert r.returncode == 0, r.stderr
+        assert back.read_bytes() == a.tobytes()
+    # one chunk length off by one: no longer consistent in itself
+    tampered = bytearray(good)
+    tampered[36 + 2 * 1000] ^= 1
+    open(side_a, "wb").write(bytes(tampered))
+    back.unlink()
+    r = run_cli(str(ca), str(back), "h", "d")
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == a.tobytes()
+    # a header length beyond the file, and a table count beyond the header: loud errors
+    whole = bytearray(ca.read_bytes())
+    broken = tmp_path / "broken.pzhf"
+    big = bytearray(whole)
+    big[4:12] = (1 << 40).to_bytes(8, "big")
+    broken.write_bytes(bytes(big))
+    r = run_cli(str(broken), str(back), "h", "d")
+    assert r.returncode == 101 and "header length" in r.stderr
+    cnt = bytearray(whole)
+    cnt[12 + 12: 12 + 20] = (1 << 50).to_bytes(8, "little")  # entry count of the bincode map
+    broken.write_bytes(bytes(cnt))
+    r = run_cli(str(broken), str(back), "h", "d")
+    assert r.returncode == 101
+
+
+def test_cli_streams_a_file_larger_than_its_pieces(tmp_path, orc):
+    """1 GiB + 96 MiB: beyond the single-upload path, so the histogram is counted
+    in 64 MiB pieces, the encoder drains 256 MiB at a time and the decoder works
+    through 64 Mi-symbol pieces (with the side file) or 32 MiB windows of the
+    stream (without); neither process may hold the whole file."""
+    n = (1 << 30) + (96 << 20) + 4321
+    data = synth.generate_host("zipf", n, seed=5)
+    src, dst, back = tmp_path / "in.bin", tmp_path / "out.pzhf", tmp_path / "back.bin"
+    src.write_bytes(data.tobytes())
+
+    def run_measured(*args):
+        """The tool as a child of its own; returns the peak resident set of its
+        address space in MiB (VmHWM of /proc/<pid>/status, sampled while it runs:
+        the rusage figure would include this test process's own size at fork)."""
+        import time
+
+        p = subprocess.Popen([CLI, *args], stderr=subprocess.PIPE)
+        peak = 0.0
+        while p.poll() is None:
+            try:
+                with open(f"/proc/{p.pid}/status") as f:
+                    for line in f:
+                        if line.startswith("VmHWM:"):
+                            peak = max(peak, int(line.split()[1]) / 1024.0)
+            except OSError:
+                pass
+            time.sleep(0.02)
+        assert p.returncode == 0, p.stderr.read().decode()
+        return peak
+
+    peaks = [run_measured(str(src), str(dst), "h", "c")]
+    want = orc.compress_with_header(data)
+    got = np.fromfile(dst, dtype=np.uint8)
+    assert got.size == len(want) and np.array_equal(got, np.frombuffer(want, dtype=np.uint8))
+    del want, got
+    peaks.append(run_measured(str(dst), str(back), "h", "d"))
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), data)
+    os.remove(str(dst) + ".hfgap")
+    back.unlink()
+    peaks.append(run_measured(str(dst), str(back), "h", "d"))
+    assert np.array_equal(np.fromfile(back, dtype=np.uint8), data)
+    print("peak resident MiB (compress, decompress with side file, without):", peaks)
+    # the file is 1.1 GiB, its stream 0.8 GiB: every process stays well below either
+    assert max(peaks) < 700, peaks
