@@ -81,6 +81,9 @@ SIGNATURES = {
                                    C.c_uint64, C.c_void_p]),
     "hf_build_gap_array": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                      C.c_uint32, C.c_void_p, C.c_void_p]),
+    "hf_shard_plan": (C.c_int, [u64p, u64p, C.c_uint32, u64p, u64p, C.POINTER(C.c_uint32), u64p,
+                                u64p, u64p]),
+    "hf_place_shard": (C.c_int, [u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64]),
     "hf_histogram_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
     "hf_encode_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                  C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, u64p]),

@@ -18,6 +18,8 @@ PROGRAMS = [
     (os.path.join(HERE, "cli", "main.cpp"), os.path.join(HERE, "bin", "hfgpu")),
     (os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp"),
      os.path.join(ROOT, "tests", "cpp", "test_mirror")),
+    (os.path.join(ROOT, "tools", "src", "adaptor_rate.cpp"),
+     os.path.join(ROOT, "tools", "bin", "adaptor_rate")),
 ]
 
 

@@ -537,6 +537,60 @@ int hf_model_to_table(const uint64_t codes[256], const uint64_t lens[256], uint6
     return hf::model_table(codes, lens, keys, syms, klens, m);
 }
 
+int hf_shard_plan(const uint64_t *hists, const uint64_t lens[256], uint32_t world, uint64_t *bits,
+                  uint64_t *start_bit, uint32_t *lead_bits, uint64_t *byte_first,
+                  uint64_t *byte_last, uint64_t *total_bits)
+{
+    if (!hists || !lens || world == 0)
+        return HF_ERR_BAD_ARG;
+    uint64_t run = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        uint64_t b = 0;
+        for (int s = 0; s < 256; ++s)
+            b += hists[(size_t)r * 256 + s] * lens[s];
+        if (bits)
+            bits[r] = b;
+        if (start_bit)
+            start_bit[r] = run;
+        if (lead_bits)
+            lead_bits[r] = (uint32_t)(run % 8);
+        if (byte_first)
+            byte_first[r] = run / 8;
+        if (byte_last)
+            byte_last[r] = (run + b + 7) / 8;
+        run += b;
+    }
+    if (total_bits)
+        *total_bits = run;
+    return HF_OK;
+}
+
+int hf_place_shard(uint8_t *whole, uint64_t whole_cap, const uint8_t *shard, uint64_t start_bit,
+                   uint64_t shard_bits)
+{
+    if (!whole || (!shard && shard_bits))
+        return HF_ERR_BAD_ARG;
+    if (shard_bits == 0)
+        return HF_OK;
+    const uint64_t first = start_bit / 8, last = (start_bit + shard_bits + 7) / 8;
+    if (last > whole_cap)
+        return HF_ERR_CAPACITY;
+    // the bytes shared with the predecessor and with the successor are OR-merged
+    // (their bits are disjoint), everything in between is copied
+    uint64_t i = 0, end = last - first;
+    if (start_bit % 8) {
+        whole[first] |= shard[0];
+        i = 1;
+    }
+    if ((start_bit + shard_bits) % 8 && end > i) {
+        whole[last - 1] |= shard[end - 1];
+        end -= 1;
+    }
+    if (end > i)
+        std::memcpy(whole + first + i, shard + i, end - i);
+    return HF_OK;
+}
+
 uint64_t hf_calculate_length(uint64_t val)
 {
     // src/huffman/encode.rs:140-149: bit length, with 0 and 1 both costing one bit

@@ -122,16 +122,27 @@ def gather_histograms(local_hist: torch.Tensor, dist):
 
 def plan_from_histograms(hists, lens, rank: int) -> ShardPlan:
     """The cross-rank exclusive scan of the shards' bit lengths, computed
-    identically on every rank from the gathered histograms."""
+    identically on every rank from the gathered histograms (hf_shard_plan of
+    the C ABI: host arithmetic, no GPU needed)."""
+    import ctypes as C
+
     import numpy as np
 
-    bits = [int(b) for b in (np.asarray(hists, dtype=np.uint64)
-                             * np.asarray(lens, dtype=np.uint64)[None, :]).sum(axis=1)]
-    start, acc = [], 0
-    for b in bits:
-        start.append(acc)
-        acc += b
-    return ShardPlan(rank, len(bits), bits, start)
+    from ._lib import HF_OK, HfError, lib, u64p
+
+    h = np.ascontiguousarray(np.asarray(hists, dtype=np.uint64))
+    if h.ndim != 2 or h.shape[1] != 256:
+        raise ValueError("expected [world, 256] histograms")
+    ln = np.ascontiguousarray(np.asarray(lens, dtype=np.uint64))
+    world = h.shape[0]
+    bits = np.zeros(world, dtype=np.uint64)
+    start = np.zeros(world, dtype=np.uint64)
+    rc = lib().hf_shard_plan(h.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), world,
+                             bits.ctypes.data_as(u64p), start.ctypes.data_as(u64p), None, None,
+                             None, None)
+    if rc != HF_OK:
+        raise HfError(rc, "hf_shard_plan")
+    return ShardPlan(rank, world, [int(b) for b in bits], [int(b) for b in start])
 
 
 def allreduce_histogram(hist: torch.Tensor, dist) -> torch.Tensor:

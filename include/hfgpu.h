@@ -279,6 +279,39 @@ HF_API int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t 
                               uint64_t in_bytes, uint64_t n_out, uint32_t chunk_syms,
                               uint16_t *d_chunk_bits, uint64_t *d_seg_off);
 
+/* ------------------------------------------------ one stream over several GPUs
+ *
+ * The reference encodes one slice in one process (Huffman::from_slice,
+ * src/huffman/mod.rs:59-65, then Encoder::write + flush, src/huffman/encode.rs:
+ * 91-136).  Cut into `world` contiguous shards, one per GPU, the same stream
+ * comes out when (1) the shards' histograms are summed before the codebook is
+ * built and (2) shard r is encoded with lead_bits[r] = start_bit[r] % 8, where
+ * start_bit is the exclusive scan of the shards' bit lengths: the shards then
+ * concatenate bytewise and only a shared boundary byte is OR-merged.
+ *
+ * hf_shard_plan: host arithmetic of step (2), identical on every rank.
+ *   hists      world x 256 counts, row r = histogram of shard r (as gathered
+ *              from the ranks; their column sums are the histogram the
+ *              codebook `lens` was built from)
+ *   bits[r]        = sum_s hists[r][s] * lens[s]
+ *   start_bit[r]   = bits[0] + ... + bits[r-1]
+ *   lead_bits[r]   = start_bit[r] % 8        (what rank r passes to hf_encode*)
+ *   byte_first[r], byte_last[r]  = [first, last) bytes of the whole stream that
+ *              shard r's local stream (lead bits included) covers
+ *   *total_bits    = bit length of the whole stream
+ * What a binding's Encoder::flush on rank r calls between the histogram
+ * exchange and its hf_encode*_async. */
+HF_API int hf_shard_plan(const uint64_t *hists, const uint64_t lens[256], uint32_t world,
+                         uint64_t *bits, uint64_t *start_bit, uint32_t *lead_bits,
+                         uint64_t *byte_first, uint64_t *byte_last, uint64_t *total_bits);
+/* Puts shard r's local stream (host memory, lead bits included, as hf_encode*
+ * produced it) at its place in the whole stream `whole` (whole_cap bytes, zero
+ * initialised, possibly already holding other shards): the bytes it may share
+ * with its predecessor and its successor are OR-merged, the rest copied.
+ * Shards may be placed in any order. */
+HF_API int hf_place_shard(uint8_t *whole, uint64_t whole_cap, const uint8_t *shard,
+                          uint64_t start_bit, uint64_t shard_bits);
+
 /* ------------------------------------------------------- host-buffer forms
  *
  * The same operations for callers whose data lives in host memory (what a

@@ -38,6 +38,26 @@ def test_library_exports_every_declared_symbol():
     assert L.hf_strerror(0) == b"ok"
 
 
+def test_rust_sys_crate_declares_the_same_functions():
+    """bindings/rust/hfgpu-sys/src/lib.rs cannot be compiled in this image (no
+    Rust toolchain): at least its list of functions and their parameter counts
+    are kept in step with include/hfgpu.h."""
+    header = open(os.path.join(ROOT, "include", "hfgpu.h")).read()
+    rust = open(os.path.join(ROOT, "bindings", "rust", "hfgpu-sys", "src", "lib.rs")).read()
+    c_decl = {m.group(1): m.group(2) for m in
+              re.finditer(r"HF_API\s+[\w\s\*]+?\b(hf_\w+)\s*\(([^;]*?)\)\s*;", header, re.S)}
+    r_decl = {m.group(1): m.group(2) for m in
+              re.finditer(r"pub fn (hf_\w+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", rust, re.S)}
+    assert set(c_decl) == set(r_decl), set(c_decl) ^ set(r_decl)
+
+    def arity(params: str) -> int:
+        params = params.strip()
+        return 0 if params in ("", "void") else params.count(",") + 1
+
+    for name in c_decl:
+        assert arity(c_decl[name]) == arity(r_decl[name]), name
+
+
 def test_lengths_kats(kats):
     for case in kats["codeword_lengths_inplace"]["cases"]:
         w = np.array(case["weights"], dtype=np.uint64)
