@@ -487,8 +487,36 @@ def test_build_gap_array_256mib_property(dev):
 
 # ----------------------------------- the benchmark configurations, full size
 
-@pytest.mark.parametrize("kind,gib", [("zipf", 1), ("uniform", 1), ("geometric", 4)])
-def test_full_size_round_trip_properties(dev, kind, gib):
+def _oracle_windows(orc, data, enc, codes, lens, win=32 << 20):
+    """The first and the last `win` symbols of a full-size stream against the
+    oracle's stream of those symbols under the same codebook.  The last window
+    starts at a segment boundary, whose bit offset the gap array gives: the
+    oracle's bits must appear in the device stream from that bit on, and the
+    stream must end with them."""
+    n = data.numel()
+    l64 = np.asarray(lens, dtype=np.uint64)
+    head = data[:win].cpu().numpy()
+    want, _ = orc.encode_slice(head, codes, lens)
+    nbits = int(l64[head].sum())
+    got = enc.data[: want.size].cpu().numpy()
+    assert np.array_equal(got[: nbits // 8], want[: nbits // 8])
+    if nbits % 8:
+        mask = (0xff << (8 - nbits % 8)) & 0xff
+        assert (got[nbits // 8] & mask) == (want[nbits // 8] & mask)
+    seg_syms = 64 * 256
+    s0 = (n - win) // seg_syms * seg_syms
+    tail = data[s0:].cpu().numpy()
+    want, _ = orc.encode_slice(tail, codes, lens)
+    nbits = int(l64[tail].sum())
+    off = int(enc.seg_off[s0 // seg_syms].item())
+    assert off + nbits == enc.total_bits
+    got = enc.data[off // 8: enc.nbytes].cpu().numpy()
+    bits = np.unpackbits(got)[off % 8: off % 8 + nbits]
+    assert np.array_equal(bits, np.unpackbits(want)[:nbits])
+
+
+@pytest.mark.parametrize("kind,gib", [("zipf", 1), ("uniform", 1), ("geometric", 4), ("zipf", 16)])
+def test_full_size_round_trip_properties(dev, orc, kind, gib):
     # size-independent properties at the sizes the benchmark configurations name:
     # the stream length is sum(hist * len), the gap array sums to it, the
     # decode returns the input, and a second encode gives the same bytes
@@ -508,6 +536,11 @@ def test_full_size_round_trip_properties(dev, kind, gib):
     out = dev.decode(enc, model)
     assert torch.equal(out, data)
     del out
+    # the configuration's own codebook (11-bit Zipf, 30-bit geometric codes) at
+    # size: both ends of the stream bit for bit against the oracle
+    _oracle_windows(orc, data, enc, codes, lens)
+    if gib >= 16:
+        assert enc.total_bits > 1 << 36 and int(enc.seg_off[ns - 1].item()) > 1 << 36
     # ... the planned encoder (batch histograms of the counting pass) included;
     # at 4 GiB its start bits exceed 32 bits
     again = dev.encode(data, model)
