@@ -258,11 +258,11 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
             if (phi < 0) {
                 e = HF_LUT_INVALID;
             } else if (plo == phi && klens[plo] <= 32) {
-                e = (uint16_t)(syms[plo] | ((uint16_t)klens[plo] << 8));
+                e = (uint16_t)HF_LUT_ENTRY(syms[plo], klens[plo]);
                 lut->max_direct_len = std::max<uint32_t>(lut->max_direct_len, klens[plo]);
             } else if (plo != phi && job.depth + job.width + HF_LUT_W2 <= 32 &&
                        lut->n_sub < HF_LUT_MAX_SUB) {
-                e = (uint16_t)(0x8000u | lut->n_sub);
+                e = (uint16_t)(HF_LUT_ESC | (lut->n_sub << 8));
                 jobs.push_back({lut->pool.size(), (job.prefix << sig) | part, job.depth + sig,
                                 HF_LUT_W2});
                 lut->pool.resize(lut->pool.size() + ((size_t)1 << HF_LUT_W2), 0);
@@ -271,11 +271,11 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
                 e = HF_LUT_SEARCH;
                 lut->needs_search = true;
             }
-            lut->has_escape = lut->has_escape || (e & 0x8000u);
+            lut->has_escape = lut->has_escape || (e & HF_LUT_ESC);
             lut->pool[job.base + i] = e;
             // a direct entry repeats for every following slot that ends before
             // the next key: fill the run instead of deriving each slot
-            if (!(e & 0x8000u)) {
+            if (!(e & HF_LUT_ESC)) {
                 const uint32_t dc = job.width - sig;
                 uint64_t part_end = (uint64_t)1 << sig;
                 if (plo + 1 < (int64_t)m)
@@ -317,21 +317,21 @@ double build_pair_lut(const DecodeLut &lut, std::vector<uint32_t> *pair)
     uint32_t slow = 0;
     for (uint32_t x = 0; x < n; ++x) {
         const uint16_t e0 = lut.pool[x];
-        const uint32_t l0 = e0 >> 8;
-        if ((e0 & 0x8000u) || l0 == 0 || l0 > w) {
+        const uint32_t l0 = HF_LUT_LEN(e0);
+        if ((e0 & HF_LUT_ESC) || l0 == 0 || l0 > w) {
             ++slow;
             continue;
         }
         // the bits behind the first code, zero filled: a second code that ends
         // inside the index is resolved by the first level whatever the fill
         const uint16_t e1 = lut.pool[(x << l0) & (n - 1)];
-        const uint32_t l1 = e1 >> 8;
-        if (l0 == w || (e1 & 0x8000u) || l1 == 0 || l0 + l1 > w) {
-            (*pair)[x] = HF_PAIR_SLOW | (uint32_t)(e0 & 0xffu) | (l0 << 16); // first symbol only
+        const uint32_t l1 = HF_LUT_LEN(e1);
+        if (l0 == w || (e1 & HF_LUT_ESC) || l1 == 0 || l0 + l1 > w) {
+            (*pair)[x] = HF_PAIR_SLOW | (HF_LUT_SYM(e0) << 8) | l0; // first symbol only
             ++slow;
             continue;
         }
-        (*pair)[x] = (uint32_t)(e0 & 0xffu) | ((uint32_t)(e1 & 0xffu) << 8) | ((l0 + l1) << 16);
+        (*pair)[x] = (HF_LUT_SYM(e0) << 8) | (HF_LUT_SYM(e1) << 16) | (l0 + l1);
     }
     return (double)slow / (double)n;
 }

@@ -9,6 +9,15 @@
 #define HF_LUT_W1 11u          // index bits of the first level
 #define HF_LUT_W2 7u           // index bits of every further level
 #define HF_LUT_MAX_SUB 32u     // sub-tables kept in LDS at most
+// A 16-bit entry is `symbol << 8 | length` (length <= 57 in the low six bits, so
+// the entry itself serves as the shift amount of a 64-bit shift, which reads
+// only those bits, and the low byte of a sum of a few entries is the sum of
+// their lengths).  Bit 7 marks an escape: `sub-table number << 8 | 0x80`, or
+// one of the two special values below.
+#define HF_LUT_ESC 0x0080u
+#define HF_LUT_ENTRY(sym, len) ((uint32_t)(sym) << 8 | (uint32_t)(len))
+#define HF_LUT_LEN(e) ((e) & 0x7fu)
+#define HF_LUT_SYM(e) ((e) >> 8)
 #define HF_LUT_SEARCH 0xFFFFu  // entry: resolve by binary search over the keys
 #define HF_LUT_INVALID 0xFFFEu // entry: window below the smallest key
 #define HF_MAX_SENTINEL 57u    // the slice decoder of the reference needs <= 57
@@ -57,9 +66,9 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
 // decodes the same whatever follows it.
 bool is_prefix_free(const uint64_t *keys, const uint8_t *klens, uint64_t m, uint32_t sentinel);
 // Two-symbol decode table over the first-level index of `lut` (prefix-free
-// models only).  Entry of index x: sym0 | sym1 << 8 | (len0 + len1) << 16 when
+// models only).  Entry of index x: sym0 << 8 | sym1 << 16 | (len0 + len1) when
 // the two codes that start at the top of x both end inside its w1 bits.
-// Otherwise HF_PAIR_SLOW is set: with sym0 | len0 << 16 when only the first
+// Otherwise HF_PAIR_SLOW is set: with sym0 << 8 | len0 when only the first
 // code ends inside the index (the decoder looks the second one up on its own),
 // with HF_PAIR_UNRESOLVED when the first level cannot resolve the first code
 // either.  Returns the fraction of the index space that is slow -- under a

@@ -157,16 +157,16 @@ __device__ inline uint32_t dec_escape(BitReader<Src> &br, uint32_t e, const uint
 {
     const uint32_t hi = (uint32_t)(br.buf >> 32);
     uint32_t used = p.w1;
-    while ((e & 0x8000u) && e < HF_LUT_INVALID) {
+    while ((e & HF_LUT_ESC) && e < HF_LUT_INVALID) {
         const uint32_t idx = (hi << used) >> (32 - HF_LUT_W2);
-        e = s_lut[(1u << p.w1) + ((e & 0x7fffu) << HF_LUT_W2) + idx];
+        e = s_lut[(1u << p.w1) + ((e >> 8) << HF_LUT_W2) + idx];
         used += HF_LUT_W2;
     }
     if (e < HF_LUT_INVALID) {
-        const uint32_t len = e >> 8;
+        const uint32_t len = HF_LUT_LEN(e);
         br.buf <<= len;
         br.bits -= (int32_t)len;
-        return e & 0xffu;
+        return HF_LUT_SYM(e);
     }
     if (e == HF_LUT_SEARCH) {
         const uint32_t pos = br.pos();
@@ -194,12 +194,12 @@ __device__ __forceinline__ uint32_t dec_symbol(BitReader<Src> &br, const uint16_
                                                uint32_t shift, const DecParams &p, bool &bad)
 {
     const uint32_t e = s_lut[(uint32_t)(br.buf >> 32) >> shift];
-    if (ESC && __builtin_expect(e & 0x8000u, 0))
+    if (ESC && __builtin_expect(e & HF_LUT_ESC, 0))
         return dec_escape(br, e, s_lut, p, bad);
-    const uint32_t len = e >> 8;
+    const uint32_t len = HF_LUT_LEN(e);
     br.buf <<= len;
     br.bits -= (int32_t)len;
-    return e & 0xffu;
+    return HF_LUT_SYM(e);
 }
 
 template <typename Src, int SPR, bool ESC>
@@ -327,16 +327,16 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel(DecParams p)
 
 // Escape entry `e` of the first level resolved from a 64-bit window whose
 // top `sentinel` bits are valid: walks the sub-tables, then falls back to the
-// predecessor search.  Returns a plain entry (len << 8 | sym); len 0 and
+// predecessor search.  Returns a plain entry (sym << 8 | len); len 0 and
 // `bad` set when the window lies below the smallest key.
 __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uint16_t *s_lut,
                                              const DecParams &p, bool &bad)
 {
     const uint32_t hi = (uint32_t)(win >> 32);
     uint32_t used = p.w1;
-    while ((e & 0x8000u) && e < HF_LUT_INVALID) {
+    while ((e & HF_LUT_ESC) && e < HF_LUT_INVALID) {
         const uint32_t idx = (hi << used) >> (32 - HF_LUT_W2);
-        e = s_lut[(1u << p.w1) + ((e & 0x7fffu) << HF_LUT_W2) + idx];
+        e = s_lut[(1u << p.w1) + ((e >> 8) << HF_LUT_W2) + idx];
         used += HF_LUT_W2;
     }
     if (e < HF_LUT_INVALID)
@@ -344,7 +344,7 @@ __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uin
     if (e == HF_LUT_SEARCH) {
         const int k = dec_predecessor(p.keys, p.m, win >> (64 - p.sentinel));
         if (k >= 0)
-            return ((uint32_t)p.klens[k] << 8) | p.ksyms[k];
+            return HF_LUT_ENTRY(p.ksyms[k], p.klens[k]);
     }
     bad = true;
     return 0;
@@ -353,23 +353,30 @@ __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uin
 // Completes a two-symbol table entry that is marked slow: the first symbol
 // comes from the entry, or from a single lookup (escapes included) when the
 // entry could not hold it; the second always from a single lookup behind it.
-// Returns the entry the table could not hold: sym0 | sym1 << 8 | (len0 + len1) << 16.
+// Returns the entry the table could not hold: sym0 << 8 | sym1 << 16 | (len0 +
+// len1).  Two codes that do not fit the 64-bit window together mark the lane
+// dirty instead (their length is reported as 0).
 __device__ inline uint32_t dec_pair_slow(uint64_t win, uint32_t e, const uint16_t *s_lut,
-                                         const DecParams &p, bool &bad)
+                                         const DecParams &p, bool &bad, bool &dirty)
 {
     const uint32_t shift = 32 - p.w1;
-    uint32_t sym0 = e & 0xffu, l0 = (e >> 16) & 63u;
+    uint32_t sym0 = (e >> 8) & 0xffu, l0 = e & 0x7fu;
     if (e & HF_PAIR_UNRESOLVED) {
         uint32_t e0 = s_lut[(uint32_t)(win >> 32) >> shift];
-        if (e0 & 0x8000u)
+        if (e0 & HF_LUT_ESC)
             e0 = dec_escape_window(win, e0, s_lut, p, bad);
-        sym0 = e0 & 0xffu, l0 = e0 >> 8;
+        sym0 = HF_LUT_SYM(e0), l0 = HF_LUT_LEN(e0);
     }
     win <<= (l0 & 63u);
     uint32_t e1 = s_lut[(uint32_t)(win >> 32) >> shift];
-    if (e1 & 0x8000u)
+    if (e1 & HF_LUT_ESC)
         e1 = dec_escape_window(win, e1, s_lut, p, bad);
-    return sym0 | ((e1 & 0xffu) << 8) | ((l0 + (e1 >> 8)) << 16);
+    uint32_t len = l0 + HF_LUT_LEN(e1);
+    if (len > 64u) {
+        dirty = true;
+        len = 0;
+    }
+    return (sym0 << 8) | (HF_LUT_SYM(e1) << 16) | len;
 }
 
 // Register-output form of the decode kernel for 64-symbol chunks.  ESC = the
@@ -579,22 +586,22 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
             const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
             uint64_t win = ((uint64_t)hi << 32) | lo;
-            uint32_t used = 0;
+            uint32_t esum = 0; // its low byte: the lengths (at most 8 x 22 + one pair of 64 bits)
 #pragma unroll
             for (int k = 0; k < K; k += 2) {
                 const int j = g + k;
                 if (j < CS) {
                     uint32_t e = s_pair[(uint32_t)(win >> 32) >> shift];
                     if (__builtin_expect((int32_t)e < 0, 0))
-                        e = dec_pair_slow(win, e, s_lut, p, bad);
-                    const uint32_t len = e >> 16;
-                    win <<= (len & 63u);
-                    used += len;
-                    // bytes j % 4 and j % 4 + 1 of the output word take the entry's low two bytes
-                    const uint32_t sel = (j & 2) ? 0x05040100u : 0x03020504u;
+                        e = dec_pair_slow(win, e, s_lut, p, bad, dirty);
+                    win <<= (e & 63u); // the entry is its own shift amount
+                    esum += e;
+                    // bytes j % 4 and j % 4 + 1 of the output word take bytes 1 and 2 of the entry
+                    const uint32_t sel = (j & 2) ? 0x06050100u : 0x03020605u;
                     outw[j >> 2] = __builtin_amdgcn_perm(e, outw[j >> 2], sel);
                 }
             }
+            const uint32_t used = esum & 0xffu;
             pos += used;
             dirty = dirty || used > 64u;
         }
@@ -619,23 +626,31 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
             const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
             uint64_t win = ((uint64_t)hi << 32) | lo;
-            uint32_t used = 0;
+            // Entries of tables without escapes have lengths of at most 32 bits:
+            // up to seven of them are summed whole and the low byte of the sum is
+            // the sum of their lengths.
+            constexpr bool BYTESUM = !ESC && K <= 7;
+            uint32_t used = 0, esum = 0;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int j = g + k;
                 if (j < CS) {
                     uint32_t e = s_lut[(uint32_t)(win >> 32) >> shift];
-                    if (ESC && __builtin_expect((e & 0x8000u) != 0, 0))
+                    if (ESC && __builtin_expect((e & HF_LUT_ESC) != 0, 0))
                         e = dec_escape_window(win, e, s_lut, p, bad);
-                    const uint32_t len = e >> 8;
-                    win <<= len;
-                    used += len;
-                    // byte j % 4 of the output word takes the entry's low byte
+                    win <<= (e & 63u); // the entry is its own shift amount
+                    if (BYTESUM)
+                        esum += e;
+                    else
+                        used += HF_LUT_LEN(e);
+                    // byte j % 4 of the output word takes byte 1 of the entry
                     constexpr uint32_t keep = 0x03020100u;
-                    const uint32_t sel = (keep & ~(0xffu << (8 * (j & 3)))) | (0x04u << (8 * (j & 3)));
+                    const uint32_t sel = (keep & ~(0xffu << (8 * (j & 3)))) | (0x05u << (8 * (j & 3)));
                     outw[j >> 2] = __builtin_amdgcn_perm(e, outw[j >> 2], sel);
                 }
             }
+            if (BYTESUM)
+                used = esum & 0xffu;
             pos += used;
             if (SPEC)
                 dirty = dirty || used > 64u;

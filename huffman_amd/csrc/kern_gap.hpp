@@ -67,13 +67,13 @@ struct GapParams {
     uint64_t *seg_off;
 };
 
-// Entry (len << 8 | sym) of the code at the head of a 64-bit window; 0 with
+// Entry (sym << 8 | len) of the code at the head of a 64-bit window; 0 with
 // `bad` set when the window lies below the smallest key.
 __device__ __forceinline__ uint32_t gap_entry(uint64_t win, const uint16_t *s_lut,
                                               const DecParams &p, bool &bad)
 {
     uint32_t e = s_lut[(uint32_t)(win >> 32) >> (32 - p.w1)];
-    if (__builtin_expect((e & 0x8000u) != 0, 0))
+    if (__builtin_expect((e & HF_LUT_ESC) != 0, 0))
         e = dec_escape_window(win, e, s_lut, p, bad);
     return e;
 }
@@ -107,7 +107,7 @@ __device__ __forceinline__ void gap_walk(const GapWords &src, const GapParams &g
 #pragma unroll 1
         for (uint32_t k = 0; k < per_window && pos < end; ++k) {
             const uint32_t e = gap_entry(win, s_lut, g.d, bad);
-            uint32_t len = e >> 8;
+            uint32_t len = HF_LUT_LEN(e);
             len = len ? len : 1u; // a wrong guess may land anywhere: keep moving
             win <<= len;
             pos += len;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_emit_kernel(GapParams g)
                 until = cs;
             }
             const uint32_t e = gap_entry(win, s_lut, g.d, bad);
-            uint32_t len = e >> 8;
+            uint32_t len = HF_LUT_LEN(e);
             len = len ? len : 1u;
             win <<= len;
             pos += len;
