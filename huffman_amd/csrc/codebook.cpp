@@ -346,7 +346,7 @@ bool prefer_padded_image(double mean_bits, double sd_bits)
         return (double)(rng >> 11) * (1.0 / 9007199254740992.0);
     };
     double cost[2] = {0, 0};
-    const int trials = 24;
+    const int trials = 12;
     for (int t = 0; t < trials; ++t) {
         double start[32];
         double at = uni() * 32.0 * 1024.0; // bit phase of the group's first chunk
@@ -357,23 +357,19 @@ bool prefer_padded_image(double mean_bits, double sd_bits)
             at += std::max(1.0, mean_bits + sd_bits * g);
         }
         for (int padded = 0; padded < 2; ++padded) {
-            uint32_t word[32];
+            // distinct words per bank (the same word is one access: broadcast);
+            // the start words ascend, so a repeated word is the previous one
+            int per_bank[32] = {0};
+            uint32_t last_word[32];
             int worst = 1;
             for (int l = 0; l < 32; ++l) {
-                const uint32_t w = (uint32_t)(start[l] / 32.0);
-                word[l] = padded ? w + (w >> 5) : w;
-            }
-            for (int l = 0; l < 32; ++l) {
-                int same_bank = 1;
-                for (int q = 0; q < l; ++q) // the same word is one access (broadcast)
-                    if ((word[q] & 31u) == (word[l] & 31u) && word[q] != word[l]) {
-                        bool counted = false;
-                        for (int r = 0; r < q; ++r)
-                            counted = counted || word[r] == word[q];
-                        if (!counted)
-                            ++same_bank;
-                    }
-                worst = std::max(worst, same_bank);
+                uint32_t w = (uint32_t)(start[l] / 32.0);
+                w = padded ? w + (w >> 5) : w;
+                const uint32_t bank = w & 31u;
+                if (per_bank[bank] == 0 || last_word[bank] != w) {
+                    last_word[bank] = w;
+                    worst = std::max(worst, ++per_bank[bank]);
+                }
             }
             cost[padded] += worst;
         }
