@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhfgpu.so")
+# HFGPU_LIB names another build of the library (A/B timing of kernel variants)
+LIB_PATH = os.path.abspath(os.environ["HFGPU_LIB"]) if os.environ.get("HFGPU_LIB") else \
+    os.path.join(_HERE, "libhfgpu.so")
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)
