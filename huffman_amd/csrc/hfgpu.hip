@@ -545,12 +545,13 @@ int hf_histogram_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uint64_t *d
     HF_HIP(ctx, hipMemsetAsync(d_hist, 0, 256 * sizeof(uint64_t), ctx->stream));
     if (n == 0)
         return HF_OK;
-    const uint64_t per_block = (uint64_t)HIST_THREADS * 16 * HIST_UNROLL;
+    const uint64_t per_block = (uint64_t)HIST_THREADS * 16 * HIST_VECS;
     uint64_t want = (n + per_block - 1) / per_block;
-    uint64_t cap = ctx->hist_grid > 0 ? (uint64_t)ctx->hist_grid : (uint64_t)ctx->num_cus * 4;
+    uint64_t cap = ctx->hist_grid > 0 ? (uint64_t)ctx->hist_grid : (uint64_t)ctx->num_cus * 2;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+    auto kern = n >= HIST_STREAM_MIN_BYTES ? hist_kernel<true> : hist_kernel<false>;
     HF_TIMED_LAUNCH(ctx, HF_TIMED_HISTOGRAM,
-                    hipLaunchKernelGGL(hist_kernel, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream,
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream,
                                        d_in, n, reinterpret_cast<unsigned long long *>(d_hist)));
     HF_HIP(ctx, hipGetLastError());
     return HF_OK;
@@ -577,7 +578,9 @@ int hf_histogram_batches_async(hf_ctx *ctx, const uint8_t *d_in, uint64_t n, uin
     const uint64_t n_batches = (n + PLAN_BATCH - 1) / PLAN_BATCH;
     uint64_t cap = ctx->hist_grid > 0 ? (uint64_t)ctx->hist_grid : (uint64_t)ctx->num_cus * 2;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(n_batches, cap));
-    auto kern = ((uintptr_t)d_in & 15) == 0 ? hist_batches_kernel<true> : hist_batches_kernel<false>;
+    auto kern = ((uintptr_t)d_in & 15) != 0  ? hist_batches_kernel<false, false>
+                : n >= HIST_STREAM_MIN_BYTES ? hist_batches_kernel<true, true>
+                                             : hist_batches_kernel<true, false>;
     HF_TIMED_LAUNCH(ctx, HF_TIMED_HISTOGRAM,
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, d_in,
                                        n, reinterpret_cast<unsigned long long *>(d_hist),
