@@ -309,13 +309,18 @@ bool is_prefix_free(const uint64_t *keys, const uint8_t *klens, uint64_t m, uint
     return true;
 }
 
-double build_pair_lut(const DecodeLut &lut, std::vector<uint32_t> *pair)
+bool build_pair_lut(const DecodeLut &lut, double max_slow, std::vector<uint32_t> *pair)
 {
     const uint32_t w = lut.w1;
     const uint32_t n = 1u << w;
+    const uint32_t slow_limit = (uint32_t)(max_slow * (double)n);
     pair->assign(n, HF_PAIR_SLOW | HF_PAIR_UNRESOLVED);
     uint32_t slow = 0;
     for (uint32_t x = 0; x < n; ++x) {
+        if (slow > slow_limit) { // most models are out after a few dozen indices
+            pair->clear();
+            return false;
+        }
         const uint16_t e0 = lut.pool[x];
         const uint32_t l0 = HF_LUT_LEN(e0);
         if ((e0 & HF_LUT_ESC) || l0 == 0 || l0 > w) {
@@ -333,7 +338,9 @@ double build_pair_lut(const DecodeLut &lut, std::vector<uint32_t> *pair)
         }
         (*pair)[x] = (HF_LUT_SYM(e0) << 8) | (HF_LUT_SYM(e1) << 16) | (l0 + l1);
     }
-    return (double)slow / (double)n;
+    if (slow > slow_limit)
+        pair->clear();
+    return slow <= slow_limit;
 }
 
 bool prefer_padded_image(double mean_bits, double sd_bits)

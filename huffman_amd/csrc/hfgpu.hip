@@ -247,8 +247,8 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     // first-level index holds two complete codes (strongly skewed streams)
     std::vector<uint32_t> pair;
     const bool prefix_free = hf::is_prefix_free(keys, klens, m, lut.sentinel);
-    if (prefix_free && lut.w1 >= 6 && hf::build_pair_lut(lut, &pair) > 0.01)
-        pair.clear();
+    if (prefix_free && lut.w1 >= 6)
+        (void)hf::build_pair_lut(lut, 0.01, &pair);
     const size_t off_pair = align_up(off_klens + 256, 16);
     const size_t total = off_pair + pair.size() * sizeof(uint32_t);
     hf_ctx::Pinned &ps = ctx->pinned[ctx->pinned_next++ % 4];

@@ -71,12 +71,13 @@ bool is_prefix_free(const uint64_t *keys, const uint8_t *klens, uint64_t m, uint
 // Otherwise HF_PAIR_SLOW is set: with sym0 << 8 | len0 when only the first
 // code ends inside the index (the decoder looks the second one up on its own),
 // with HF_PAIR_UNRESOLVED when the first level cannot resolve the first code
-// either.  Returns the fraction of the index space that is slow -- under a
-// well-compressed stream, where every index is about equally likely, the
-// probability that a lookup needs the fix-up.
+// either.  The table is only worth having when few indices are slow: under a
+// well-compressed stream every index is about equally likely, so the slow
+// fraction of the index space is the probability that a lookup needs the
+// fix-up.  Returns false, with `pair` empty, when it exceeds `max_slow`.
 #define HF_PAIR_SLOW 0x80000000u
 #define HF_PAIR_UNRESOLVED 0x40000000u
-double build_pair_lut(const DecodeLut &lut, std::vector<uint32_t> *pair);
+bool build_pair_lut(const DecodeLut &lut, double max_slow, std::vector<uint32_t> *pair);
 // Layout of the decoder's LDS image of the stream.  Lane l of a wave starts
 // reading near word l * mean_bits / 32 (chunk l of the segment), and 32 lanes
 // are served per LDS cycle, one word per bank (word index mod 32): chunk sizes

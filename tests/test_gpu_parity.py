@@ -62,6 +62,51 @@ def test_histogram_unaligned_input(dev, orc, offset):
     assert np.array_equal(got, orc.histogram(data[offset:]))
 
 
+@pytest.mark.parametrize("grid", [1, 3, 7])
+@pytest.mark.parametrize("n,off", [(20 * 65536 + 12345, 0), (9 * 65536, 16), (7 * 65536 + 15, 5)])
+def test_histogram_few_workgroups_many_spans(dev, orc, grid, n, off):
+    # a workgroup that stays for several 64 KiB spans keeps refilling its load
+    # registers: with the default grid only inputs of 32 MiB and more get there
+    host = synth.generate_host("zipf", n + off, seed=n + grid)
+    data = to_gpu(host)[off:]
+    ctx = dev.Context.get(data.device)
+    ctx.set_option("hist_grid", grid)
+    try:
+        plain = dev.histogram_async(data)
+        bh = dev.new_batch_hist(n, data.device)
+        with_batches = dev.histogram_async(data, batch_hist=bh)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("hist_grid", 0)
+    want = orc.histogram(host[off:])
+    assert np.array_equal(plain.cpu().numpy().astype(np.uint64), want)
+    assert np.array_equal(with_batches.cpu().numpy().astype(np.uint64), want)
+    nb = (n + 65535) // 65536
+    got = bh[: nb * 256].cpu().numpy().reshape(nb, 256)
+    for b in range(nb):
+        assert np.array_equal(got[b], np.bincount(host[off + b * 65536: off + min(n, (b + 1) * 65536)],
+                                                  minlength=256)), b
+
+
+@pytest.mark.parametrize("off", [0, 16, 3])
+def test_histogram_streaming_loads_large_input(dev, off):
+    # inputs of 256 MiB and more are read with non-temporal loads
+    n = (1 << 28) + 12345
+    t = synth.generate_device("zipf", n + off, seed=7)[off:]
+    want = torch.bincount(t.int(), minlength=256).cpu().numpy()
+    plain = dev.histogram_async(t)
+    bh = dev.new_batch_hist(n, t.device)
+    with_batches = dev.histogram_async(t, batch_hist=bh)
+    torch.cuda.synchronize()
+    assert np.array_equal(plain.cpu().numpy(), want)
+    assert np.array_equal(with_batches.cpu().numpy(), want)
+    nb = (n + 65535) // 65536
+    sums = bh[: nb * 256].view(nb, 256).to(torch.int64).sum(dim=0).cpu().numpy()
+    assert np.array_equal(sums, want)
+    last = torch.bincount(t[(nb - 1) * 65536:].int(), minlength=256).cpu().numpy()
+    assert np.array_equal(bh[(nb - 1) * 256: nb * 256].cpu().numpy(), last)
+
+
 def test_histogram_kat(dev, kats):
     k = kats["histogram"]
     h = dev.histogram(to_gpu(np.array(k["data"], dtype=np.uint8)))
