@@ -107,10 +107,11 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const uint8_t *__res
         }
 #pragma nounroll
         for (; sp < n_spans; sp += gridDim.x) {
-            // after the last span the refill reads it again (unused): no
-            // branch in the loop, exact wait counts
-            const uint64_t nx = sp + gridDim.x < n_spans ? sp + gridDim.x : sp;
-            src = vin + nx * SPAN + threadIdx.x;
+            // after the last span every refill reads the span's first 16 bytes
+            // again (unused): no branch in the loop, exact wait counts
+            const bool more = sp + gridDim.x < n_spans;
+            const uint32_t step = more ? HIST_THREADS : 0;
+            src = vin + (more ? (sp + gridDim.x) * SPAN + threadIdx.x : sp * SPAN);
 #pragma unroll
             for (int k = 0; k < HIST_VECS; ++k) {
                 hist_add4(col, x[k].x);
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_kernel(const uint8_t *__res
                 hist_add4(col, x[k].z);
                 hist_add4(col, x[k].w);
                 __builtin_amdgcn_sched_barrier(0); // the refill goes into the registers just counted
-                x[k] = hist_load<STREAM>(src + k * HIST_THREADS);
+                x[k] = hist_load<STREAM>(src + k * step);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -199,10 +200,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_batches_kernel(
         }
 #pragma nounroll
         for (; b < n_whole; b += gridDim.x) {
-            // after the workgroup's last whole batch the refill reads that
-            // batch again (unused): no branch in the loop, exact wait counts
-            const uint64_t src = b + gridDim.x < n_whole ? b + gridDim.x : b;
-            vin = reinterpret_cast<const uint4 *>(in + src * PLAN_BATCH) + threadIdx.x;
+            // after the workgroup's last whole batch every refill reads that
+            // batch's first 16 bytes again (unused): no branch in the loop,
+            // exact wait counts
+            const bool more = b + gridDim.x < n_whole;
+            const uint32_t step = more ? HIST_THREADS : 0;
+            vin = reinterpret_cast<const uint4 *>(in + (more ? b + gridDim.x : b) * PLAN_BATCH) +
+                  (more ? threadIdx.x : 0u);
 #pragma unroll
             for (int k = 0; k < PLAN_VECS; ++k) {
                 hist_add4(col, x[k].x);
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_batches_kernel(
                 hist_add4(col, x[k].z);
                 hist_add4(col, x[k].w);
                 __builtin_amdgcn_sched_barrier(0); // the refill goes into the registers just counted
-                x[k] = hist_load<STREAM>(vin + k * HIST_THREADS);
+                x[k] = hist_load<STREAM>(vin + k * step);
                 __builtin_amdgcn_sched_barrier(0);
             }
             hist_batch_sum(bins, batch_hist, b, running);
