@@ -586,14 +586,21 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
             const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
             uint64_t win = ((uint64_t)hi << 32) | lo;
-            uint32_t esum = 0; // its low byte: the lengths (at most 8 x 22 + one pair of 64 bits)
+            // The low byte of the sum of the entries is the sum of their lengths
+            // as long as that stays below 256: a pair from the table has at most
+            // w1 bits (8 x 11), a completed one up to 64.  Completed pairs that
+            // take the window past its 64 bits mark the lane dirty on the spot,
+            // so the byte is exact (at most 64 + 88) whenever it is used.
+            uint32_t esum = 0;
 #pragma unroll
             for (int k = 0; k < K; k += 2) {
                 const int j = g + k;
                 if (j < CS) {
                     uint32_t e = s_pair[(uint32_t)(win >> 32) >> shift];
-                    if (__builtin_expect((int32_t)e < 0, 0))
+                    if (__builtin_expect((int32_t)e < 0, 0)) {
                         e = dec_pair_slow(win, e, s_lut, p, bad, dirty);
+                        dirty = dirty || (esum & 0xffu) + (e & 0x7fu) > 64u;
+                    }
                     win <<= (e & 63u); // the entry is its own shift amount
                     esum += e;
                     // bytes j % 4 and j % 4 + 1 of the output word take bytes 1 and 2 of the entry

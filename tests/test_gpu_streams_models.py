@@ -118,6 +118,40 @@ def test_fixed_length_long_codes_decode(dev, orc, chunk_syms, width, nsym):
     assert np.array_equal(dev.decode(enc, dmodel).cpu().numpy(), data)
 
 
+@pytest.mark.parametrize("chunk_syms", [64, 128, 256])
+@pytest.mark.parametrize("nsym,growth,heavy", [(34, 2.0, 2), (34, 2.0, 34), (20, 2.3, 20), (48, 1.7, 6),
+                                               (58, 1.62, 58)])
+def test_steep_codebook_on_data_that_does_not_follow_it(dev, orc, chunk_syms, nsym, growth, heavy):
+    """A codebook for counts that grow like growth^k (lengths 1..nsym - 1: the
+    decoder gets a two-symbol table and a speculative window width chosen for
+    data that follows the model) applied to data in which the long codes are as
+    frequent as the short ones: nearly every window of the fast path overruns,
+    so every lane falls back, and all three decoders must still agree with the
+    reference's.  (Several completed pairs in one window once wrapped the byte
+    that sums their lengths.)"""
+    hist = np.zeros(256, dtype=np.uint64)
+    hist[100: 100 + nsym] = np.maximum(1, growth ** np.arange(nsym)[::-1]).astype(np.uint64)
+    codes, lens = orc.generate_extended_codewords(hist)
+    assert int(lens.max()) <= 57
+    rng = np.random.default_rng(nsym * 1000 + heavy)
+    n = 148255
+    w = np.full(nsym, 1.0)
+    w[:heavy] = 50.0  # the first `heavy` symbols (the longest codes) dominate
+    data = (100 + rng.choice(nsym, size=n, p=w / w.sum())).astype(np.uint8)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model, chunk_syms=chunk_syms)
+    want, _ = orc.encode_slice(data, codes, lens)
+    stream = enc.stream().cpu().numpy()
+    assert np.array_equal(stream, want)
+    assert np.array_equal(dev.decode(enc, model).cpu().numpy(), data)
+    cb, so = dev.build_gap_array(enc.data, enc.nbytes, model, n, chunk_syms)
+    nc, ns = dev.gap_layout(n, chunk_syms)
+    assert torch.equal(cb[:nc], enc.chunk_bits[:nc]) and torch.equal(so[:ns], enc.seg_off[:ns])
+    keys, syms, kl = orc.to_btreemap(codes, lens)
+    dmodel = dev.DeviceModel(table=(keys, syms, kl, orc.sentinel(lens)))
+    assert np.array_equal(dev.decode(enc, dmodel).cpu().numpy(), data)
+
+
 def test_context_calls_leave_the_current_device_alone(dev, orc):
     """Every entry point switches to its context's device for the call only."""
     from huffman_amd._lib import lib

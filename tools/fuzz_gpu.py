@@ -1,0 +1,161 @@
+"""Randomised differential run of the device path against the CPU oracle.
+python tools/fuzz_gpu.py [cases] [first seed]
+
+Every case draws an alphabet, a weight family (uniform, Zipf, geometric,
+Fibonacci-like for very long codes, Dirichlet), a size, an input alignment, a
+chunk size and lead bits, and checks: both counting passes against the oracle's
+histogram, the codebook, the stream of the three encoder modes bit for bit,
+the gap arrays (encoder's against the rebuilt one), and the decoders.
+It is a search tool, not part of the test suite: the suite holds the cases it
+found as fixed parametrisations."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import oracle as orc  # noqa: E402
+from huffman_amd import _lib, device as dev  # noqa: E402
+
+orc.build()
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+
+
+def weights(rng, a):
+    fam = rng.integers(0, 6)
+    k = np.arange(1, a + 1, dtype=np.float64)
+    if fam == 0:
+        w = np.ones(a)
+    elif fam == 1:
+        w = k ** -rng.uniform(0.3, 3.0)
+    elif fam == 2:
+        w = rng.uniform(0.2, 0.8) ** k
+    elif fam == 3:  # Fibonacci-like: code lengths grow by one per symbol
+        w = 1.0 / (1.6180339887 ** np.minimum(k, rng.integers(8, 60)))
+    elif fam == 4:
+        w = rng.dirichlet(np.full(a, rng.uniform(0.05, 2.0))) + 1e-12
+    else:  # a few heavy symbols and a flat tail
+        w = np.full(a, 1.0)
+        w[: max(1, a // 16)] = rng.uniform(10, 1000)
+    return fam, w / w.sum()
+
+
+def shifted(stream, lead, total_bits):
+    bits = np.unpackbits(stream)[:total_bits]
+    out = np.concatenate([np.zeros(lead, dtype=np.uint8), bits])
+    return np.packbits(out)
+
+
+def run_case(seed):
+    rng = np.random.default_rng(seed)
+    foreign = rng.integers(0, 3) == 0
+    a = int(rng.choice([1, 2, 3, 5, 17, 64, 200, 256]))
+    if foreign:
+        a = int(rng.integers(2, 70))
+    fam, w = weights(rng, a)
+    n = int(np.exp(rng.uniform(0, np.log(3e6))))
+    if rng.integers(0, 8) == 0:
+        n = int(rng.choice([1, 63, 64, 65, 16384, 65536, 65537, 4 * 65536, 1 << 20]))
+    perm = rng.permutation(256)[:a].astype(np.uint8)
+    host = perm[rng.choice(a, size=n, p=w)]
+    off = int(rng.choice([0, 0, 1, 5, 16]))
+    cs = int(rng.choice([64, 64, 128, 256]))
+    lead = int(rng.choice([0, 0, 0, 3, 7]))
+    tag = f"seed {seed}: a={a} fam={fam} foreign={int(foreign)} n={n} off={off} cs={cs} lead={lead}"
+    buf = torch.empty(n + off, dtype=torch.uint8, device="cuda")
+    buf[off:] = torch.from_numpy(host).cuda()
+    t = buf[off:]
+    ctx = dev.Context.get(t.device)
+
+    want_hist = orc.histogram(host)
+    model_hist = want_hist
+    if foreign:
+        # a codebook that does not come from this data: counts that grow like
+        # r^k give code lengths up to the number of symbols, and the data uses
+        # the long codes as often as the short ones
+        r = rng.uniform(1.3, 2.6)
+        model_hist = np.zeros(256, dtype=np.uint64)
+        grow = np.minimum(r ** np.arange(a, dtype=np.float64), 2.0 ** 62)
+        model_hist[perm.astype(np.int64)] = np.maximum(1, grow[::-1]).astype(np.uint64)
+    bh = dev.new_batch_hist(n, t.device)
+    h1 = dev.histogram_async(t).cpu().numpy().astype(np.uint64)
+    h2 = dev.histogram_async(t, batch_hist=bh).cpu().numpy().astype(np.uint64)
+    assert np.array_equal(h1, want_hist), tag + " plain histogram"
+    assert np.array_equal(h2, want_hist), tag + " batch histogram"
+    try:
+        ocodes, olens = orc.generate_extended_codewords(model_hist)
+    except ValueError:
+        # lengths of 64 and more: the reference's shifts overflow there, both sides refuse
+        try:
+            dev.build_codebook(model_hist)
+        except dev.HfError as e:
+            return tag + f" codebook refused by both ({e.status})"
+        raise AssertionError(tag + " the oracle refuses this histogram, the library does not")
+    codes, lens = dev.build_codebook(model_hist)
+    assert np.array_equal(codes, ocodes) and np.array_equal(lens, olens), tag + " codebook"
+    maxlen = int(lens.max())
+    try:
+        model = dev.DeviceModel(codes, lens)
+    except dev.HfError as e:
+        assert maxlen > 57 and e.status == _lib.HF_ERR_UNSUPPORTED, tag + f" model: {e}"
+        return tag + f" maxlen={maxlen} (unsupported, as documented)"
+    want, _ = orc.encode_slice(host, codes, lens)
+    total_bits = int((want_hist.astype(object) * lens.astype(object)).sum())
+    want = shifted(want, lead, total_bits) if lead else want
+    streams = {}
+    for mode in ("three-kernel", "chained", "planned"):
+        ctx.set_option("enc_mode", 0 if mode == "three-kernel" else 1)
+        bufs = dev.EncodeBuffers(model, n, cs, lead_bits=lead)
+        bufs.data.fill_(0xA5)
+        dev.encode_async(t, model, bufs, lead_bits=lead, plan=bh if mode == "planned" else None)
+        res = bufs.result.cpu().numpy()
+        assert int(res[1]) == 0, tag + f" {mode}: flags {int(res[1])}"
+        assert int(res[0]) == total_bits, tag + f" {mode}: total bits"
+        nbytes = (lead + total_bits + 7) // 8
+        got = bufs.data[:nbytes].cpu().numpy()
+        assert np.array_equal(got, want), tag + f" {mode}: stream differs"
+        streams[mode] = bufs
+    ctx.set_option("enc_mode", 1)
+    bufs = streams["planned"]
+    nbytes = (lead + total_bits + 7) // 8
+    nc, ns = dev.gap_layout(n, cs)
+    for mode, b in streams.items():
+        assert torch.equal(b.chunk_bits[:nc], bufs.chunk_bits[:nc]), tag + f" {mode}: chunk_bits"
+        assert torch.equal(b.seg_off[:ns], bufs.seg_off[:ns]), tag + f" {mode}: seg_off"
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dres = torch.zeros(4, dtype=torch.int64, device="cuda")
+    if lead == 0:
+        dev.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
+        if int(dres[1].item()) != 0 or not torch.equal(out, t):
+            bad = torch.nonzero(out != t).flatten()
+            for dbg in (128, 256):  # without the pair table; the BitReader kernel
+                ctx.set_option("debug", dbg)
+                o2 = torch.zeros_like(out)
+                dev.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, o2, dres)
+                print(f"  debug {dbg}: {int((o2 != t).sum().item())} wrong symbols", flush=True)
+            ctx.set_option("debug", 0)
+            raise AssertionError(tag + f" decode with gap array: flags {int(dres[1].item())}, maxlen {maxlen}, "
+                                 f"{bad.numel()} wrong symbols, first at {bad[:8].tolist()}, "
+                                 f"lens {sorted(set(int(x) for x in lens if x))}")
+        cb, so = dev.build_gap_array(bufs.data, nbytes, model, n, cs)
+        assert torch.equal(cb[:nc], bufs.chunk_bits[:nc]), tag + " rebuilt chunk_bits"
+        assert torch.equal(so[:ns], bufs.seg_off[:ns]), tag + " rebuilt seg_off"
+        if n <= 200000:
+            out2 = dev.decode_serial(bufs.data, nbytes, model, n)
+            assert torch.equal(out2, t), tag + " serial decode"
+    else:
+        # the stream starts `lead` bits into the buffer: decode with bit_base = -lead is not
+        # part of the interface, so the shifted stream is checked through its bytes only
+        pass
+    return tag + f" maxlen={maxlen} ok"
+
+
+if __name__ == "__main__":
+    t0 = time.time()
+    for s in range(seed0, seed0 + cases):
+        msg = run_case(s)
+        if (s - seed0) % 500 == 0:
+            print(f"[{time.time() - t0:6.1f}s] {msg}", flush=True)
+    print(f"{cases} cases passed in {time.time() - t0:.1f} s")
