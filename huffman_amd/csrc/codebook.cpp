@@ -291,20 +291,23 @@ int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *k
     return HF_OK;
 }
 
-bool is_prefix_free(const uint64_t *keys, const uint8_t *klens, uint64_t m, uint32_t sentinel)
+bool is_complete_prefix_code(const uint64_t *keys, const uint8_t *klens, uint64_t m,
+                             uint32_t sentinel)
 {
-    if (m == 0 || sentinel == 0 || sentinel > 64)
+    if (m == 0 || sentinel == 0 || sentinel > 64 || keys[0] != 0)
         return false;
-    // with the keys (left-aligned codes) in ascending order, no key may fall
-    // inside the range its predecessor's code covers
+    // with the keys (left-aligned codes) in ascending order, every key must
+    // start exactly where the range that its predecessor's code covers ends,
+    // and the last range must end with the key space
     for (uint64_t i = 0; i < m; ++i) {
         if (klens[i] == 0 || klens[i] > sentinel)
             return false;
-        if (i + 1 < m) {
-            const uint64_t span = (uint64_t)1 << (sentinel - klens[i]);
-            if (keys[i + 1] <= keys[i] || keys[i + 1] - keys[i] < span)
-                return false;
-        }
+        const uint64_t last = keys[i] + (((uint64_t)1 << (sentinel - klens[i])) - 1u);
+        if (last < keys[i])
+            return false;
+        if (i + 1 < m ? keys[i + 1] != last + 1 || last + 1 == 0
+                      : last != (sentinel == 64 ? ~(uint64_t)0 : ((uint64_t)1 << sentinel) - 1u))
+            return false;
     }
     return true;
 }
@@ -389,7 +392,7 @@ uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t
 {
     if (m == 0 || sentinel == 0 || sentinel > 64 || 8 * sentinel <= 64)
         return 0; // the plain K = 64 / sentinel is at least 8 wide already
-    if (!is_prefix_free(keys, klens, m, sentinel))
+    if (!is_complete_prefix_code(keys, klens, m, sentinel))
         return 0;
     double d[65] = {0};
     double kraft = 0;

@@ -243,11 +243,10 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     const size_t off_keys = align_up(off_lut + lut.pool.size() * 2, 16);
     const size_t off_ksyms = off_keys + 256 * sizeof(uint64_t);
     const size_t off_klens = off_ksyms + 256;
-    // two-symbol decode table: only for prefix-free models in which nearly every
+    // two-symbol decode table: only for complete prefix codes in which nearly every
     // first-level index holds two complete codes (strongly skewed streams)
     std::vector<uint32_t> pair;
-    const bool prefix_free = hf::is_prefix_free(keys, klens, m, lut.sentinel);
-    if (prefix_free && lut.w1 >= 6)
+    if (lut.w1 >= 6 && hf::is_complete_prefix_code(keys, klens, m, lut.sentinel))
         (void)hf::build_pair_lut(lut, 0.01, &pair);
     const size_t off_pair = align_up(off_klens + 256, 16);
     const size_t total = off_pair + pair.size() * sizeof(uint32_t);

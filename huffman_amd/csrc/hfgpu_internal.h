@@ -52,21 +52,28 @@ int model_table(const uint64_t codes[256], const uint64_t lens[256], uint64_t ke
 int pick_merge_width(const uint64_t lens[256], bool *speculative);
 // Codes the decoder may take from one 64-bit window without checking (16, 8, 7
 // or 6), or 0 when only sentinel-many bits per code are safe.  Only for models
-// that are prefix free (a code that fits the window then decodes the same
-// whatever follows it): the largest width for which, with symbols drawn with
-// the probabilities 2^-len that the lengths imply, fewer than one chunk of 64
+// that are complete prefix codes (a code that fits the window then decodes the
+// same whatever follows it, and one that does not fit never decodes as one
+// that does): the largest width for which, with symbols drawn with the
+// probabilities 2^-len that the lengths imply, fewer than one chunk of 64
 // symbols in ten million (16, 8) or in a hundred thousand (7, 6) holds a group
 // that exceeds 64 bits.
 uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t m,
                             uint32_t sentinel);
 int build_decode_lut(const uint64_t *keys, const uint8_t *syms, const uint8_t *klens, uint64_t m,
                      uint64_t sentinel, DecodeLut *lut);
-// True when no code of the table is a prefix of another one (keys ascending,
-// left-aligned codes): a code that lies completely inside a bit window then
-// decodes the same whatever follows it.
-bool is_prefix_free(const uint64_t *keys, const uint8_t *klens, uint64_t m, uint32_t sentinel);
-// Two-symbol decode table over the first-level index of `lut` (prefix-free
-// models only).  Entry of index x: sym0 << 8 | sym1 << 16 | (len0 + len1) when
+// True when the table is a complete prefix code: no code is a prefix of another
+// one and every bit window starts with exactly one of them (Kraft sum 1; what
+// the Huffman construction yields for two or more symbols).  Only then does a
+// window that holds the first v bits of a longer code, whatever follows them,
+// never decode as a code of at most v bits: in a table with unused code space
+// the predecessor rule maps such a window to the nearest smaller key, which
+// can be short.  The decoder's shortcuts that look at windows whose tail is
+// not valid (speculative window widths, the two-symbol table) rely on this.
+bool is_complete_prefix_code(const uint64_t *keys, const uint8_t *klens, uint64_t m,
+                             uint32_t sentinel);
+// Two-symbol decode table over the first-level index of `lut` (complete prefix
+// codes only).  Entry of index x: sym0 << 8 | sym1 << 16 | (len0 + len1) when
 // the two codes that start at the top of x both end inside its w1 bits.
 // Otherwise HF_PAIR_SLOW is set: with sym0 << 8 | len0 when only the first
 // code ends inside the index (the decoder looks the second one up on its own),

@@ -404,7 +404,7 @@ __device__ inline uint32_t dec_pair_slow(uint64_t win, uint32_t e, const uint16_
     do {                                                                                      \
     } while (0)
 #endif
-// PAIR = strongly skewed prefix-free models (short codes dominate): a second
+// PAIR = strongly skewed complete prefix codes (short codes dominate): a second
 // table over the same first-level index holds, for almost every index, the TWO
 // symbols whose codes start there and their combined length, so one lookup,
 // one shift and one byte permute serve two symbols; the few indices whose
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
         // No reader state besides the bit position: every K symbols the lane
         // rebuilds a 64-bit window from the three image words at its position;
         // no refill branches.  Either K * sentinel <= 64, so the window cannot
-        // run dry, or (SPEC, prefix-free models only) the host chose K so that
+        // run dry, or (SPEC, complete prefix codes only) the host chose K so that
         // K codes practically never exceed 64 bits; a lane to which it happens
         // anyway is marked dirty and decodes its chunk again at the end.
         uint32_t pos = s_lo + excl;

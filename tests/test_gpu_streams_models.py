@@ -152,6 +152,78 @@ def test_steep_codebook_on_data_that_does_not_follow_it(dev, orc, chunk_syms, ns
     assert np.array_equal(dev.decode(enc, dmodel).cpu().numpy(), data)
 
 
+def test_prefix_code_with_unused_code_space(dev, orc):
+    """Three codes, 000000 / 111100011 / 1100111010011011: no code is a prefix
+    of another, but most of the code space is unused, and there the reference's
+    predecessor rule answers with the nearest smaller key.  A window that holds
+    only the first 14 bits of the 16-bit code, zero filled, lies in such a gap
+    and reads as the 6-bit code -- which fits the window: a decoder that takes
+    several codes from one window on the strength of 'what fits is right' goes
+    wrong here, so those shortcuts are reserved for complete codes."""
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    for sym, code, ln in [(229, 0b0, 6), (27, 0b111100011, 9), (155, 0b1100111010011011, 16)]:
+        codes[sym], lens[sym] = code, ln
+    rng = np.random.default_rng(413)
+    n = 204355
+    data = np.array([229, 27, 155], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    stream, _ = orc.encode_slice(data, codes, lens)
+    want = orc.decode_read(stream, codes, lens, n)[:n]
+    assert np.array_equal(want, data)
+    model = dev.DeviceModel(codes, lens)
+    for cs in (64, 128, 256):
+        enc = dev.encode(to_gpu(data), model, chunk_syms=cs)
+        assert np.array_equal(enc.stream().cpu().numpy(), stream)
+        assert np.array_equal(dev.decode(enc, model).cpu().numpy(), want)
+        cb, so = dev.build_gap_array(enc.data, enc.nbytes, model, n, cs)
+        nc, ns = dev.gap_layout(n, cs)
+        assert torch.equal(cb[:nc], enc.chunk_bits[:nc]) and torch.equal(so[:ns], enc.seg_off[:ns])
+
+
+@pytest.mark.parametrize("seed", [7, 99, 413, 1234, 2024, 31337])
+def test_random_key_tables_decode_like_the_reference(dev, orc, seed):
+    """Arbitrary tables (distinct left-aligned keys, key 0 present, codes may be
+    prefixes of each other or leave code space unused): the bare stream goes
+    through the gap-array rebuild and the chunk-parallel decoder and must come
+    out as the reference's sequential predecessor decode returns it."""
+    import ctypes as C
+
+    from huffman_amd import _lib
+    from huffman_amd._lib import u8p
+
+    rng = np.random.default_rng(seed)
+    nsym, maxlen = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    keys, used = set(), []
+    for i, s in enumerate(rng.permutation(256)[:nsym]):
+        for _ in range(50):
+            ln = int(rng.integers(1, maxlen + 1))
+            code = 0 if i == 0 else int(rng.integers(0, 1 << ln))
+            key = code << (maxlen - ln)
+            if key not in keys:
+                keys.add(key)
+                codes[s], lens[s] = code, ln
+                used.append(s)
+                break
+    sent = int(lens.max())
+    if len({int(codes[s]) << (sent - int(lens[s])) for s in used}) != len(used):
+        pytest.skip("keys collide once aligned to the longest length in use")
+    n = 150001
+    data = np.array(used, dtype=np.uint8)[rng.integers(0, len(used), size=n)]
+    stream, _ = orc.encode_slice(data, codes, lens)
+    try:
+        want = orc.decode_read(stream, codes, lens, n)[:n]
+    except ValueError:
+        pytest.skip("the reference's own assertion (decode/mod.rs:207-210) refuses this stream")
+    model = dev.DeviceModel(codes, lens)
+    back = np.zeros(n, dtype=np.uint8)
+    rc = _lib.lib().hf_decode_host(model.ctx.handle, model.handle, stream.ctypes.data_as(u8p),
+                                   stream.size, n, 64, None, None, back.ctypes.data_as(u8p))
+    assert rc == _lib.HF_OK, _lib.lib().hf_last_error(model.ctx.handle)
+    assert np.array_equal(back, want)
+
+
 def test_context_calls_leave_the_current_device_alone(dev, orc):
     """Every entry point switches to its context's device for the call only."""
     from huffman_amd._lib import lib
