@@ -13,13 +13,19 @@ SOURCES = [os.path.join(CSRC, "hfgpu.hip"), os.path.join(CSRC, "codebook.cpp")]
 HEADERS = [os.path.join(ROOT, "include", "hfgpu.h"), os.path.join(CSRC, "hfgpu_internal.h")] + [
     os.path.join(CSRC, h) for h in ("dev_common.hpp", "kern_hist.hpp", "kern_encode.hpp",
                                     "kern_decode.hpp", "kern_gap.hpp")]
-# host programs on top of the C++ mirror (include/hfgpu.hpp): (source, executable)
+# host programs on top of the C++ mirror (include/hfgpu.hpp):
+# (source, executable, extra compiler flags, extra linker flags)
+ORACLE_DIR = os.path.join(ROOT, "oracle")
 PROGRAMS = [
-    (os.path.join(HERE, "cli", "main.cpp"), os.path.join(HERE, "bin", "hfgpu")),
+    (os.path.join(HERE, "cli", "main.cpp"), os.path.join(HERE, "bin", "hfgpu"), [], []),
     (os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp"),
-     os.path.join(ROOT, "tests", "cpp", "test_mirror")),
+     os.path.join(ROOT, "tests", "cpp", "test_mirror"), [], []),
     (os.path.join(ROOT, "tools", "src", "adaptor_rate.cpp"),
-     os.path.join(ROOT, "tools", "bin", "adaptor_rate")),
+     os.path.join(ROOT, "tools", "bin", "adaptor_rate"), [], []),
+    # test program: the mirror's adaptors with small pieces against the CPU oracle
+    (os.path.join(ROOT, "tests", "fuzz", "fuzz_mirror.cpp"),
+     os.path.join(ROOT, "tests", "fuzz", "fuzz_mirror"), ["-DHFGPU_PIECE_DIVISOR=4096"],
+     ["-L" + ORACLE_DIR, "-loracle", "-Wl,-rpath,$ORIGIN/../../oracle"]),
 ]
 
 
@@ -41,9 +47,11 @@ def build_programs(force: bool = False, verbose: bool = False) -> list[str]:
     """Host-only C++ programs; they reach the GPU through libhfgpu.so alone."""
     hpp = os.path.join(ROOT, "include", "hfgpu.hpp")
     out = []
-    for src, exe in PROGRAMS:
+    for src, exe, cflags, ldflags in PROGRAMS:
         out.append(exe)
         deps = [src, hpp, LIB, *HEADERS]
+        if ldflags and not os.path.exists(os.path.join(ORACLE_DIR, "liboracle.so")):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
         if not force and os.path.exists(exe) and all(
                 os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
             continue
@@ -51,9 +59,9 @@ def build_programs(force: bool = False, verbose: bool = False) -> list[str]:
         obj = exe + ".o"
         rel = os.path.relpath(HERE, os.path.dirname(exe))
         cmds = [
-            ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-c", src,
-             "-o", obj],
-            [hipcc(), obj, "-o", exe, "-L" + HERE, "-lhfgpu", "-Wl,-rpath,$ORIGIN/" + rel],
+            ["g++", "-O2", "-std=c++17", "-Wall", *cflags, "-I" + os.path.join(ROOT, "include"), "-c",
+             src, "-o", obj],
+            [hipcc(), obj, "-o", exe, "-L" + HERE, "-lhfgpu", "-Wl,-rpath,$ORIGIN/" + rel, *ldflags],
         ]
         for cmd in cmds:
             if verbose:

@@ -29,6 +29,14 @@
 
 #include "hfgpu.h"
 
+// The streaming adaptors move data in pieces (64 MiB of input per histogram
+// call, 256 MiB staged per encode, 64 Mi symbols or a 32 MiB window per
+// decode, files up to 1 GiB in one upload).  Test programs divide all of them
+// by this factor so that inputs of a few MiB cross every piece boundary.
+#ifndef HFGPU_PIECE_DIVISOR
+#define HFGPU_PIECE_DIVISOR 1
+#endif
+
 namespace rscompress_huffman {
 
 using usize = std::uint64_t;
@@ -91,7 +99,7 @@ namespace stats {
 // generate_histogram (src/stats.rs:13-28): the reader is drained into a piece
 // of PIECE bytes at a time; every piece is counted on the GPU and the 256
 // counts are summed, so the host holds one piece whatever the input's size.
-constexpr std::size_t HISTOGRAM_PIECE = std::size_t(64) << 20;
+constexpr std::size_t HISTOGRAM_PIECE = (std::size_t(64) << 20) / HFGPU_PIECE_DIVISOR;
 template <class Reader>
 std::array<usize, 256> generate_histogram(Reader &reader)
 {
@@ -400,7 +408,7 @@ class Encoder {
     // bytes staged before the device encodes them: a file larger than this is
     // compressed piece by piece (pieces are whole segments, so the gap arrays
     // concatenate and only a shared boundary byte is carried over)
-    static constexpr std::size_t STAGE_LIMIT = std::size_t(256) << 20;
+    static constexpr std::size_t STAGE_LIMIT = (std::size_t(256) << 20) / HFGPU_PIECE_DIVISOR;
 
     W inner;
     const Model *model;
@@ -675,8 +683,9 @@ inline std::vector<u8> read(const std::vector<u8> &data, const Model &model, usi
 template <class R>
 class Decoder {
   public:
-    static constexpr usize PIECE_SYMS = usize(64) << 20;    // with a gap array: symbols per piece
-    static constexpr std::size_t WINDOW_BYTES = std::size_t(32) << 20; // without: stream bytes per window
+    // with a gap array: symbols per piece; without: stream bytes per window
+    static constexpr usize PIECE_SYMS = (usize(64) << 20) / HFGPU_PIECE_DIVISOR;
+    static constexpr std::size_t WINDOW_BYTES = (std::size_t(32) << 20) / HFGPU_PIECE_DIVISOR;
 
     // Decoder::new (decode/mod.rs:29-47)
     template <class W>
@@ -986,7 +995,7 @@ inline void stream_compress_with_header_information(const std::string &source,
         // bytes written are the same as on the general path below.
         std::ifstream sz(source, std::ios::binary | std::ios::ate);
         const std::uint64_t size = sz ? (std::uint64_t)sz.tellg() : 0;
-        constexpr std::uint64_t SINGLE_UPLOAD_LIMIT = std::uint64_t(1) << 30;
+        constexpr std::uint64_t SINGLE_UPLOAD_LIMIT = (std::uint64_t(1) << 30) / HFGPU_PIECE_DIVISOR;
         if (size > 0 && size <= SINGLE_UPLOAD_LIMIT) {
             std::vector<u8> data(size);
             if (reader.read(data.data(), size) != size)

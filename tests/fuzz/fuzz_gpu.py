@@ -1,5 +1,5 @@
 """Randomised differential run of the device path against the CPU oracle.
-python tools/fuzz_gpu.py [cases] [first seed]
+python tests/fuzz/fuzz_gpu.py [cases] [first seed]
 
 Every case draws an alphabet, a weight family (uniform, Zipf, geometric,
 Fibonacci-like for very long codes, Dirichlet), a size, an input alignment, a

@@ -1,6 +1,6 @@
 """Randomised differential run of the host-buffer entry points, of arbitrary
 (also not prefix-free) models and of sharded streams against the CPU oracle.
-python tools/fuzz_host.py [cases] [first seed]
+python tests/fuzz/fuzz_host.py [cases] [first seed]
 
 Per case one of:
   model   a random table of distinct left-aligned keys (key 0 included, codes
