@@ -126,7 +126,9 @@ static std::vector<u8> read_file(const std::string &path)
 static void run_case(uint64_t seed, const std::string &dir)
 {
     Rng r(seed);
-    const std::size_t n = r() % 16 == 0 ? uniform(r, 1, 300) : 1 + log_uniform(r, 3u << 20);
+    std::size_t n = r() % 16 == 0 ? uniform(r, 1, 300) : 1 + log_uniform(r, 3u << 20);
+    if (r() % 8 == 0) // whole segments, whole staging buffers: nothing left for the last piece
+        n = (std::size_t)uniform(r, 1, 40) * (r() % 2 ? 16384 : 65536);
     const auto data = random_data(r, n);
     g_tag = "seed " + std::to_string(seed) + " n=" + std::to_string(n);
 

@@ -722,6 +722,36 @@ def test_models_created_and_used_on_different_streams(dev, orc):
         assert np.array_equal(back, data)
 
 
+@pytest.mark.parametrize("chunk_syms", [64, 128, 256])
+@pytest.mark.parametrize("shape", ["runs", "iid"])
+def test_decode_many_segments_per_cu(dev, orc, chunk_syms, shape):
+    """More segments than CUs, so that several work-groups share a CU: the
+    128-symbol decoder once went wrong only in work-groups that were not the
+    first on their CU (from segment 256 on), on any data.  Runs of one symbol
+    make every chunk the same size, the other extreme for the image layout."""
+    rng = np.random.default_rng(chunk_syms)
+    n = 700 * 256 * chunk_syms + 12345 if chunk_syms < 256 else 400 * 256 * chunk_syms + 77
+    alphabet = np.array([86, 111, 214], dtype=np.uint8)
+    if shape == "runs":
+        starts = np.sort(rng.integers(0, n, size=n // 40))
+        sym = rng.integers(0, 3, size=starts.size + 1)
+        host = alphabet[sym[np.searchsorted(starts, np.arange(n), side="right")]]
+    else:
+        host = alphabet[rng.integers(0, 3, size=n)]
+    t = to_gpu(host)
+    codes, lens = dev.build_codebook(dev.histogram(t))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(t, model, chunk_syms=chunk_syms)
+    for _ in range(3):
+        got = dev.decode(enc, model)
+        wrong = torch.nonzero(got != t).flatten()
+        assert wrong.numel() == 0, (f"{wrong.numel()} wrong symbols, first in segment "
+                                    f"{int(wrong[0]) // (256 * chunk_syms)}")
+    sample = slice(0, 1 << 20)
+    want, _ = orc.encode_slice(host[sample], codes, lens)
+    assert np.array_equal(enc.stream()[: want.size - 1].cpu().numpy(), want[:-1])
+
+
 # ---- counting pass that records a histogram per 65536 symbols, and the
 # ---- encoder that takes every batch's place in the stream from them
 
