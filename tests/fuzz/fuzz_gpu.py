@@ -147,9 +147,26 @@ def run_case(seed):
     for mode, b in streams.items():
         assert torch.equal(b.chunk_bits[:nc], bufs.chunk_bits[:nc]), tag + f" {mode}: chunk_bits"
         assert torch.equal(b.seg_off[:ns], bufs.seg_off[:ns]), tag + f" {mode}: seg_off"
+    if n <= 300000 and maxlen <= 57:
+        # Encoder::write's return value and counters, call by call, against the oracle's encoder
+        oe = orc.Encoder(codes, lens)
+        state = [0, 64, 0]
+        at = 0
+        while at < n:
+            k = int(min(n - at, rng.integers(1, 70000)))
+            want_ret = oe.write(host[at: at + k])
+            ret, state = dev.encoder_write_value(t[at: at + k], codes, lens, state)
+            assert ret == want_ret and state[2] == oe.writeout, tag + f" write() value at {at}: {ret} vs {want_ret}"
+            at += k
+    # a decode-only model built from the key table (what a file header carries)
+    keys, ksyms, kl = orc.to_btreemap(codes, lens)
+    tmodel = dev.DeviceModel(table=(keys, ksyms, kl, orc.sentinel(lens)))
     out = torch.zeros(n, dtype=torch.uint8, device="cuda")
     dres = torch.zeros(4, dtype=torch.int64, device="cuda")
     if lead == 0:
+        dev.decode_async(bufs.data, (total_bits + 7) // 8, tmodel, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
+        assert int(dres[1].item()) == 0 and torch.equal(out, t), tag + " decode with a table model"
+        out.zero_()
         dev.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
         if int(dres[1].item()) != 0 or not torch.equal(out, t):
             bad = torch.nonzero(out != t).flatten()
