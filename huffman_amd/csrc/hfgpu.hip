@@ -114,6 +114,7 @@ struct hf_model {
     int enc_group = 1; // codes the encoder merges per append: 4, 2 or 1
     bool enc_spec = false; // a merged group can exceed 32 bits
     bool has_encode = false;
+    bool bytewise = false;    // every one of the 256 symbols has an 8-bit code: encoding is a byte map
     bool lut_escapes = false; // the decode table holds entries with the escape bit
     double mean_bits = 8.0; // code length of a symbol drawn with probability 2^-len
     bool regular_chunks = false; // 64-symbol chunks sit on few LDS banks unless the image is padded
@@ -656,6 +657,7 @@ int hf_model_create(hf_ctx *ctx, const uint64_t codes[256], const uint64_t lens[
     mod->ctx = ctx;
     mod->maxlen = (uint32_t)maxlen;
     mod->has_encode = true;
+    mod->bytewise = std::all_of(lens, lens + 256, [](uint64_t l) { return l == 8; });
     mod->enc_group = group;
     mod->enc_spec = speculative;
     rc = upload_model(ctx, mod, enc, enc2, lut, keys, syms, klens, m);
@@ -790,6 +792,25 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
             return fail(ctx, HF_ERR_CAPACITY, "hf_encode: output buffer too small");
         if (bytes)
             HF_HIP(ctx, hipMemsetAsync(d_out, 0, bytes, ctx->stream));
+        return HF_OK;
+    }
+    if (model->bytewise && lead_bits == 0 && !(ctx->debug & 32)) {
+        // 8 bits per symbol throughout: a byte map, no scratch, no scan (enc_bytes_kernel)
+        if (d_batch_hist)
+            HF_HIP(ctx, hipMemsetAsync(d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
+        const uint64_t spans = (n >> 4) / ((uint64_t)ENCB_VECS * ENCB_THREADS);
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spans, (uint64_t)ctx->num_cus * 2));
+        const uint32_t cs = d_chunk_bits ? chunk_syms : 64;
+        auto kern = enc_bytes_kernel;
+        if (!fixed_scratch)
+            HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE,
+                            hipLaunchKernelGGL(kern, dim3(grid), dim3(ENCB_THREADS), 0, ctx->stream,
+                                               d_in, n, model->d_enc, d_out, out_cap, cs,
+                                               d_chunk_bits, d_seg_off, d_result));
+        else
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(ENCB_THREADS), 0, ctx->stream, d_in, n,
+                               model->d_enc, d_out, out_cap, cs, d_chunk_bits, d_seg_off, d_result);
+        HF_HIP(ctx, hipGetLastError());
         return HF_OK;
     }
     const uint64_t n_tiles64 = (n + ENC_TILE - 1) / ENC_TILE;

@@ -998,6 +998,91 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
 }
 
 
+// A model in which every one of the 256 symbols has an 8-bit code (what the
+// Huffman construction gives data that does not compress: encrypted or already
+// compressed bytes) turns the encoder into a byte map: stream byte i is the
+// code of symbol i, every chunk has 8 x chunk_syms bits, nothing needs a scan.
+// Runs at the rate of a copy.  Eight 16-byte loads per lane are in flight (the
+// register that was just mapped is refilled at once, as in the counting pass;
+// non-temporal loads make this kernel 3 % faster and the decoder that reads
+// the stream next 6 % slower, so the loads are plain).
+constexpr int ENCB_THREADS = 512;
+constexpr int ENCB_VECS = 8;
+
+__device__ __forceinline__ uint32_t encb_map4(const uint8_t *s_code, uint32_t v)
+{
+    const uint32_t a = s_code[v & 0xffu], b = s_code[(v >> 8) & 0xffu];
+    const uint32_t c = s_code[(v >> 16) & 0xffu], d = s_code[v >> 24];
+    return a | (b << 8) | (c << 16) | (d << 24);
+}
+
+__global__ __launch_bounds__(ENCB_THREADS) void enc_bytes_kernel(
+    const uint8_t *__restrict__ in, uint64_t n, const uint64_t *__restrict__ tab,
+    uint8_t *__restrict__ out, uint64_t out_cap, uint32_t chunk_syms,
+    uint16_t *__restrict__ chunk_bits, uint64_t *__restrict__ seg_off, uint64_t *__restrict__ result)
+{
+    __shared__ __align__(16) uint8_t s_code[256];
+    if (threadIdx.x < 256)
+        s_code[threadIdx.x] = (uint8_t)(tab[threadIdx.x] >> 6); // entries are code << 6 | len
+    if (out_cap < n) { // (uniform) nothing is written into a buffer that cannot hold the stream
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            atomicOr((unsigned long long *)&result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_CAPACITY);
+        return;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        result[HF_RES_TOTAL_BITS] = 8ull * n;
+    // gap array: chunk c has 8 x (its symbols) bits, segment s starts at bit 8 x 256 x chunk_syms x s
+    if (chunk_bits) {
+        const uint64_t n_chunks = (n + chunk_syms - 1) / chunk_syms;
+        for (uint64_t c = (uint64_t)blockIdx.x * ENCB_THREADS + threadIdx.x; c < n_chunks;
+             c += (uint64_t)gridDim.x * ENCB_THREADS) {
+            const uint64_t left = n - c * chunk_syms;
+            chunk_bits[c] = (uint16_t)(8u * (uint32_t)(left < chunk_syms ? left : chunk_syms));
+            if ((c % HF_SEG_CHUNKS) == 0)
+                seg_off[c / HF_SEG_CHUNKS] = 8ull * c * chunk_syms;
+        }
+    }
+    const bool vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    constexpr uint64_t SPAN = (uint64_t)ENCB_VECS * ENCB_THREADS; // 16-byte units per span
+    const uint64_t n_spans = vec ? (n >> 4) / SPAN : 0;
+    const uint4 *vin = reinterpret_cast<const uint4 *>(in);
+    uint4 *vout = reinterpret_cast<uint4 *>(out);
+    uint64_t sp = blockIdx.x;
+    if (sp < n_spans) {
+        uint4 x[ENCB_VECS];
+        const uint4 *src = vin + sp * SPAN + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < ENCB_VECS; ++k) {
+            x[k] = src[k * ENCB_THREADS];
+            __builtin_amdgcn_sched_barrier(0); // in the order in which the loop refills them
+        }
+#pragma nounroll
+        for (; sp < n_spans; sp += gridDim.x) {
+            // after the last span every refill reads that span's first unit again (unused)
+            const bool more = sp + gridDim.x < n_spans;
+            const uint32_t step = more ? ENCB_THREADS : 0;
+            src = vin + (more ? (sp + gridDim.x) * SPAN + threadIdx.x : sp * SPAN);
+            uint4 *dst = vout + sp * SPAN + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < ENCB_VECS; ++k) {
+                uint4 y;
+                y.x = encb_map4(s_code, x[k].x), y.y = encb_map4(s_code, x[k].y);
+                y.z = encb_map4(s_code, x[k].z), y.w = encb_map4(s_code, x[k].w);
+                dst[k * ENCB_THREADS] = y;
+                __builtin_amdgcn_sched_barrier(0); // the refill goes into the registers just mapped
+                x[k] = src[k * step];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // what the spans leave over (everything, for buffers that are not 16-byte aligned)
+    for (uint64_t i = n_spans * SPAN * 16 + (uint64_t)blockIdx.x * ENCB_THREADS + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * ENCB_THREADS)
+        out[i] = s_code[in[i]];
+}
+
+
 // Exact emission schedule of Encoder::write (src/huffman/encode.rs:91-116)
 // for one call: one lane replays put (:57-66) and cleanup (:67-83) over the
 // symbols so that the call's return value and the counters match the

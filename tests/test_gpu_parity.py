@@ -158,6 +158,57 @@ def test_encode_other_distributions(dev, orc, kind, n):
     check_encode(dev, orc, data, codes, lens)
 
 
+@pytest.mark.parametrize("n,off,cs", [(1, 0, 64), (15, 0, 64), (16, 0, 128), (65536, 0, 64), (65537, 3, 256),
+                                      (3 * 65536 + 17, 16, 64), ((1 << 22) + 5, 0, 128), ((1 << 22) + 5, 1, 64)])
+def test_encode_all_codes_eight_bits_is_a_byte_map(dev, orc, n, off, cs):
+    """Every symbol with an 8-bit code (incompressible data): the encoder maps
+    bytes (enc_bytes_kernel); stream, gap array and totals against the oracle,
+    the general encoder (lead bits force it) against the same stream shifted,
+    and a buffer that is too small."""
+    hist = np.full(256, 1000, dtype=np.uint64)
+    hist[::7] += 1  # ties broken differently from the identity: codes are a permutation
+    codes, lens = orc.generate_extended_codewords(hist)
+    assert set(int(x) for x in lens) == {8}
+    rng = np.random.default_rng(n)
+    host = rng.integers(0, 256, size=n + off, dtype=np.uint8)
+    t = to_gpu(host)[off:]
+    model = dev.DeviceModel(codes, lens)
+    want, _ = orc.encode_slice(host[off:], codes, lens)
+    assert want.size == n
+    enc = dev.encode(t, model, chunk_syms=cs)
+    assert enc.total_bits == 8 * n
+    assert np.array_equal(enc.stream().cpu().numpy(), want)
+    nc, ns = dev.gap_layout(n, cs)
+    cb = enc.chunk_bits[:nc].cpu().numpy().astype(np.uint16).astype(np.int64)
+    assert int(cb.sum()) == 8 * n and (cb[:-1] == 8 * cs).all()
+    assert np.array_equal(enc.seg_off[:ns].cpu().numpy(), np.arange(ns, dtype=np.int64) * 8 * 256 * cs)
+    assert np.array_equal(dev.decode(enc, model).cpu().numpy(), host[off:])
+    # planned entry point and the one that allocates nothing take the same path
+    bh = dev.new_batch_hist(n, t.device)
+    dev.histogram_async(t, batch_hist=bh)
+    for fn in (dev.encode_async, dev.encode_noalloc_async):
+        bufs = dev.EncodeBuffers(model, n, cs)
+        bufs.data.fill_(0x77)
+        fn(t, model, bufs, plan=bh)
+        assert bufs.result.tolist()[:2] == [8 * n, 0]
+        assert np.array_equal(bufs.data[:n].cpu().numpy(), want)
+        assert torch.equal(bufs.chunk_bits[:nc], enc.chunk_bits[:nc])
+    # lead bits: the general encoder, same bits three places further on
+    shifted = dev.encode(t, model, chunk_syms=cs, lead_bits=3)
+    bits = np.concatenate([np.zeros(3, np.uint8), np.unpackbits(want)])
+    assert np.array_equal(shifted.stream().cpu().numpy(), np.packbits(bits))
+    if n > 16:
+        with pytest.raises(dev.HfError) as e:
+            dev.encode(t, model, chunk_syms=cs, out_cap=(n - 1) & ~3)
+        assert e.value.status == _lib_status("HF_ERR_CAPACITY")
+
+
+def _lib_status(name):
+    from huffman_amd import _lib
+
+    return getattr(_lib, name)
+
+
 @pytest.mark.parametrize("chunk_syms", [128, 256])
 def test_encode_chunk_sizes(dev, orc, chunk_syms):
     data = synth.generate_host("zipf", 123457, seed=5)

@@ -19,7 +19,7 @@ entry = {"source": label}
 for name, v in sorted(json.load(open(summary)).items(), key=lambda kv: kv[0].startswith("hist_batches")):
     if "hbm_read_bytes_corrected" not in v or "hbm_write_bytes" not in v:
         continue
-    key = "histogram" if name.startswith("hist") else ("encode" if name.startswith("enc_pack") else
+    key = "histogram" if name.startswith("hist") else ("encode" if name.startswith(("enc_pack", "enc_bytes")) else
                                                        ("decode" if name.startswith("dec_kernel") else None))
     if key:
         entry[key] = int(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
