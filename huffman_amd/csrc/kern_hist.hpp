@@ -44,8 +44,6 @@ __device__ __forceinline__ uint4 hist_load(const uint4 *p)
     return *p;
 }
 
- // 16-byte vectors in flight per lane
-
 __device__ __forceinline__ void hist_add4(uint32_t *col, uint32_t v)
 {
     __hip_atomic_fetch_add(col + ((v & 0xffu) << 5), 1u, __ATOMIC_RELAXED,
