@@ -49,6 +49,40 @@ def shifted(stream, lead, total_bits):
     return np.packbits(out)
 
 
+def diagnose_decode(ctx, model, bufs, nbytes, n, cs, t):
+    """What a wrong decode looks like: again as it was (is it reproducible?), with the
+    other image layout, without the pair table, through the BitReader kernel; where in
+    the chunks, lanes and segments the wrong symbols sit; and segments 256..511 on
+    their own (as work-groups 0..255 of a launch: is it the data or the place?)."""
+    seg = 256 * cs
+    dres = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for dbg, what in ((0, "as it was"), (0, "again"), (64, "other image layout"),
+                      (128, "without pair table"), (256, "BitReader kernel")):
+        ctx.set_option("debug", dbg)
+        o2 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dev.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, o2, dres)
+        w = torch.nonzero(o2 != t).flatten()
+        segs = sorted(set((w // seg).tolist()))
+        print(f"  {what}: {w.numel()} wrong symbols in {len(segs)} segments {segs[:12]}", flush=True)
+        if dbg == 0 and segs:
+            units = torch.bincount(((w % cs) // 16).int(), minlength=cs // 16).tolist()
+            lanes = torch.bincount(((w // cs) % 256).int(), minlength=256)
+            firsts = {}
+            for pos, c in zip(w.tolist(), (w // cs).tolist()):
+                firsts.setdefault(c, pos % cs)
+            fh = np.bincount(np.array(list(firsts.values())), minlength=cs)
+            print(f"    per 16-byte unit of the chunk {units}; per wave {lanes.view(4, 64).sum(dim=1).tolist()}; "
+                  f"first wrong symbol of a chunk: " + " ".join(f"{i}:{int(v)}" for i, v in enumerate(fh) if v),
+                  flush=True)
+    ctx.set_option("debug", 0)
+    if n > 600 * seg:
+        o3 = torch.zeros(256 * seg, dtype=torch.uint8, device="cuda")
+        dev.decode_async(bufs.data, nbytes, model, 256 * seg, cs, bufs.chunk_bits[256 * 256:],
+                         bufs.seg_off[256:], o3, dres)
+        print(f"  segments 256..511 in a launch of their own: "
+              f"{int((o3 != t[256 * seg: 512 * seg]).sum().item())} wrong symbols", flush=True)
+
+
 def run_case(seed):
     rng = np.random.default_rng(seed)
     foreign = rng.integers(0, 3) == 0
@@ -170,64 +204,7 @@ def run_case(seed):
         dev.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
         if int(dres[1].item()) != 0 or not torch.equal(out, t):
             bad = torch.nonzero(out != t).flatten()
-            seg = 256 * cs
-            for dbg in (0, 0, 64):  # again as it was (twice: is it reproducible?); the other image layout
-                ctx.set_option("debug", dbg)
-                o2 = torch.zeros_like(out)
-                dev.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, o2, dres)
-                w = torch.nonzero(o2 != t).flatten()
-                segs = sorted(set((w // seg).tolist()))
-                print(f"  debug {dbg}: {w.numel()} wrong symbols in segments {segs[:12]}, shape {shape}, "
-                      f"first {w[:4].tolist()} last {w[-4:].tolist()}", flush=True)
-                if segs:
-                    units = torch.bincount(((w % cs) // 16).int(), minlength=cs // 16).tolist()
-                    lanes = torch.bincount(((w // cs) % 256).int(), minlength=256)
-                    print(f"    wrong per 16-byte unit of the chunk {units}; per wave of lanes "
-                          f"{lanes.view(4, 64).sum(dim=1).tolist()}; per lane%4 {lanes.view(64, 4).sum(dim=0).tolist()}; "
-                          f"segments {len(segs)} min {segs[0]} max {segs[-1]}", flush=True)
-                    ch = (w // cs)
-                    firsts = {}
-                    for pos_, c_ in zip(w.tolist(), ch.tolist()):
-                        if c_ not in firsts:
-                            firsts[c_] = pos_ % cs
-                    fh = np.bincount(np.array(list(firsts.values())), minlength=cs)
-                    print(f"    first wrong symbol per chunk ({len(firsts)} chunks): " +
-                          " ".join(f"{i}:{int(v)}" for i, v in enumerate(fh) if v), flush=True)
-                    s0 = segs[0]
-                    ws = w[(w // seg) == s0] - s0 * seg
-                    chunks = sorted(set((ws // cs).tolist()))
-                    cbits = bufs.chunk_bits[s0 * 256:(s0 + 1) * 256].cpu().numpy().astype(np.uint16)
-                    c0 = int(w[0]) // cs
-                    names = {int(x): chr(65 + k % 26) for k, x in enumerate(sorted(int(y) for y in range(256) if lens[y]))}
-                    for cc in ():
-                        g = "".join(names[int(v)] for v in o2[cc * cs:(cc + 1) * cs].tolist())
-                        e = "".join(names[int(v)] for v in t[cc * cs:(cc + 1) * cs].tolist())
-                        print(f"    chunk {cc} (lane {cc % 256}) bits {int(bufs.chunk_bits[cc].item()) & 0xffff}\n      want {e}\n      got  {g}", flush=True)
-                    wa = w[(w // seg) == s0][:12]
-                    print("    got/want:", [(int(o2[i]), int(t[i]), int(lens[int(o2[i])]), int(lens[int(t[i])])) for i in wa.tolist()],
-                          "codes", {int(x): (int(codes[x]), int(lens[x])) for x in range(256) if lens[x]}, flush=True)
-                    print(f"    segment {s0}: {ws.numel()} wrong in chunks {chunks[:40]}; first offsets in chunk "
-                          f"{[int(x) for x in (ws % cs)[:10].tolist()]}; seg bits {int(cbits.sum())} "
-                          f"seg_off {int(bufs.seg_off[s0].item())} (mod 128: {int(bufs.seg_off[s0].item()) % 128})", flush=True)
-            ctx.set_option("debug", 0)
-            if n > 600 * seg:
-                # segments 256..511 alone, as work-groups 0..255 of their own launch
-                o3 = torch.zeros(256 * seg, dtype=torch.uint8, device="cuda")
-                dev.decode_async(bufs.data, nbytes, model, 256 * seg, cs, bufs.chunk_bits[256 * 256:],
-                                 bufs.seg_off[256:], o3, dres)
-                print(f"  segments 256..511 in a launch of their own: "
-                      f"{int((o3 != t[256 * seg: 512 * seg]).sum().item())} wrong symbols", flush=True)
-                o3 = torch.zeros(512 * seg, dtype=torch.uint8, device="cuda")
-                dev.decode_async(bufs.data, nbytes, model, 512 * seg, cs, bufs.chunk_bits, bufs.seg_off, o3, dres)
-                wr = torch.nonzero(o3 != t[:512 * seg]).flatten()
-                print(f"  segments 0..511 in one launch: {wr.numel()} wrong symbols, first segment "
-                      f"{int(wr[0]) // seg if wr.numel() else -1}", flush=True)
-            for dbg in (128, 256):  # without the pair table; the BitReader kernel
-                ctx.set_option("debug", dbg)
-                o2 = torch.zeros_like(out)
-                dev.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, o2, dres)
-                print(f"  debug {dbg}: {int((o2 != t).sum().item())} wrong symbols", flush=True)
-            ctx.set_option("debug", 0)
+            diagnose_decode(ctx, model, bufs, nbytes, n, cs, t)
             raise AssertionError(tag + f" decode with gap array: flags {int(dres[1].item())}, maxlen {maxlen}, "
                                  f"{bad.numel()} wrong symbols, first at {bad[:8].tolist()}, "
                                  f"lens {sorted(set(int(x) for x in lens if x))}")
