@@ -1,7 +1,7 @@
 import sys, torch
 sys.path.insert(0, ".")
 from huffman_amd import device as hd, synth
-n = 1 << 30
+n = (int(sys.argv[1]) if len(sys.argv) > 1 else 1) << 30
 data = synth.generate_device("zipf", n, seed=2024)
 d_hist = torch.empty(256, dtype=torch.int64, device="cuda")
 plan = hd.new_batch_hist(n, data.device)
