@@ -15,15 +15,19 @@ namespace {
 
 // ----------------------------------------------------------------- helpers
 
+// Inclusive scan over the 64 lanes of a wave with data-parallel primitives
+// (no LDS crossbar round trips): shifts inside each row of 16 lanes, then lane
+// 15 of rows 0 and 2 is broadcast to rows 1 and 3, then lane 31 to rows 2 and 3.
+// Lanes without a source, and rows masked out, add zero.
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d)
-            v += t;
-    }
+    constexpr int ROW_SHR = 0x110, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ROW_SHR + 1, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ROW_SHR + 2, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ROW_SHR + 4, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ROW_SHR + 8, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ROW_BCAST15, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ROW_BCAST31, 0xc, 0xf, false);
     return v;
 }
 

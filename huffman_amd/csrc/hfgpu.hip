@@ -526,7 +526,7 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
         ctx->kernel_timing = value != 0;
     else if (!std::strcmp(name, "dec_trace")) // device address, 128 bytes per segment; 0 = off
         ctx->dec_trace = reinterpret_cast<uint64_t *>((uintptr_t)value);
-    else if (!std::strcmp(name, "debug") && value >= 0 && value < 512)
+    else if (!std::strcmp(name, "debug") && value >= 0 && value < 1024)
         ctx->debug = (int)value;
     else
         return fail(ctx, HF_ERR_BAD_ARG, "unknown option or value out of range: %s", name);
@@ -905,12 +905,26 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
                              : enc_pack_kernel<G, false, false, false>))
         kern = g == 4 ? HF_PICK(4) : (g == 2 ? HF_PICK(2) : HF_PICK(1));
 #undef HF_PICK
+        // complete planned batches of a model for the carry sink: one lookup per symbol
+        // (debug bit 512, timing experiments: the two-lookup kernel instead)
+        uint32_t grid_wgs = grid;
+        if (planned && lean && carry && model->maxlen <= ENC_STREAM_MAXLEN && !(ctx->debug & 512)) {
+            // merged codes of at most 22 bits travel as one register per group
+            const bool packed = (uint32_t)g * model->maxlen <= 22u;
+            // (two codes of at most ENC_STREAM_MAXLEN bits always are)
+            kern = g == 4 ? (packed ? enc_pack_stream_kernel<4, true> : enc_pack_stream_kernel<4, false>)
+                          : enc_pack_stream_kernel<2, true>;
+            const uint32_t slots = (uint32_t)ctx->num_cus * ENC_STREAM_WGS_PER_CU;
+            p.wg_batches = (grid + slots - 1) / slots;
+            p.n_wg_batches = grid;
+            grid_wgs = (grid + p.wg_batches - 1) / p.wg_batches;
+        }
         // (only the launch over the complete batches is timed: the ragged rest is one workgroup)
         if (lean && !fixed_scratch)
             HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE,
-                            hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), 0, ctx->stream, p));
+                            hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(ENC_THREADS), 0, ctx->stream, p));
         else
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), 0, ctx->stream, p);
+            hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(ENC_THREADS), 0, ctx->stream, p);
         if (chained && lean) // the follow-up launch numbers its own workgroups from zero again
             p.ticket += 1;
     }

@@ -82,6 +82,8 @@ struct EncParams {
     uint64_t timeout_ticks;   // in 100 MHz wall-clock ticks
     uint32_t n_tiles;
     uint32_t first_batch; // batch index of this launch's first workgroup
+    uint32_t wg_batches;   // enc_pack_stream_kernel: consecutive batches per workgroup
+    uint32_t n_wg_batches; //   and batches of the launch
     uint32_t debug;       // timing experiments only: bit mask of phases to skip
 };
 
@@ -271,6 +273,18 @@ struct EncSinkCarry {
         acc = (acc << (y & 63u)) | code;
         uint32_t next;
         const bool full = __builtin_add_overflow(nbl, y, &next);
+        nbl = next;
+        if (full)
+            __hip_atomic_fetch_or(enc_slot_ptr<PAD>(stg, w), (uint32_t)(acc >> (nbl >> 27)),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        w += full ? 1 : 0;
+    }
+    // x = code | len << 27: the code bits only add to the junk below bit 27
+    __device__ __forceinline__ void append_packed(uint32_t x)
+    {
+        acc = (acc << (x >> 27)) | (x & 0x07ffffffu);
+        uint32_t next;
+        const bool full = __builtin_add_overflow(nbl, x, &next);
         nbl = next;
         if (full)
             __hip_atomic_fetch_or(enc_slot_ptr<PAD>(stg, w), (uint32_t)(acc >> (nbl >> 27)),
@@ -647,7 +661,7 @@ __device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, 
 // Second half of an image pass: complete the tile's last word from the
 // symbols that follow it (last pass only) and copy the pass's words out with
 // coalesced byte-swapped 16-byte stores, clearing the image on the way.
-template <bool PAD>
+template <bool PAD, uint32_t WINW = ENC_WINW>
 __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *stg,
                                                 uint32_t la_bits, uint32_t la_have,
                                                 uint64_t E, uint64_t gbase,
@@ -655,7 +669,7 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
                                                 uint32_t need, uint32_t nwords, uint32_t wlo,
                                                 bool reuse)
 {
-    const uint32_t whi = wlo + ENC_WINW;
+    const uint32_t whi = wlo + WINW;
     const bool last_pass = nwords - 1 < whi;
     // the word that holds the tile's last bit is completed by the first `need`
     // bits of what follows the tile
@@ -994,6 +1008,234 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
             for (int q = 0; q < ENC_SPT / 4; ++q)
                 raw[u][q] = raw[u + 1][q];
         }
+    }
+}
+
+// Planned encode of complete batches with a model whose merged groups of G
+// codes stay below 32 bits (the carry sink's condition): every symbol is
+// looked up ONCE and the input is requested one tile ahead all the time.
+// enc_pack_kernel reads the length table for the scan and the {code, len}
+// table again for the packing, because a chained batch must publish its bit
+// total before it packs anything, and it requests a whole batch of symbols in
+// one burst and then computes for several times as long.  A planned run of
+// batches knows its start bit beforehand, so a workgroup takes a contiguous
+// run of tiles (p.wg_batches batches) one tile after the other:
+//   1. look the tile's symbols up, merge G codes at a time and keep the merged
+//      groups in registers; the length words also add up to the thread's bit
+//      total;
+//   2. wave scan, one LDS hand-over between the waves (one barrier): the
+//      thread's bit offset inside the tile and the tile's total; the gap array
+//      comes from the neighbours' offsets by shuffles;
+//   3. the groups go from the registers through the carry sink into the image;
+//   4. last word, copy-out (enc_finish_pass, one more barrier).
+// The next tile's symbols are requested before step 2's barrier, so about a
+// tile per workgroup is always on its way.  The bits that complete a tile's
+// last word are worked out by one wave per tile (wave t mod 8) from 64 symbols
+// that it requested a tile earlier.  Every batch's bit total is compared with
+// the planned one: batch histograms that belong to other data set
+// HF_FLAG_PLAN (the stream is then void; every store is still checked against
+// the buffer's capacity).
+// PACKED: a group is one register, code | len << 27 (merged codes of at most
+// 22 bits): added to the sink's counter as it is -- the code bits of a tile's
+// groups stay below bit 27 in sum -- at the price of one shift per group to
+// get the length alone; otherwise two registers, code and len | len << 27.
+// Codes of at most ENC_STREAM_MAXLEN bits: a tile's part of the stream always
+// fits the image, so this kernel has no second image pass.
+constexpr uint32_t ENC_STREAM_MAXLEN = 11;
+constexpr uint32_t ENC_STREAM_WINW = ENC_TILE * ENC_STREAM_MAXLEN / 32 + 8;
+// One image is enough: the barrier of the next tile's scan lies between a
+// tile's copy-out and the next packing.  25 KB of LDS and 64 registers: four
+// workgroups per CU.
+constexpr int ENC_STREAM_WAVES = 8;  // waves per SIMD
+constexpr uint32_t ENC_STREAM_WGS_PER_CU = 4;
+template <int G, bool PACKED>
+__global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream_kernel(EncParams p)
+{
+    constexpr bool PAD = false;
+    constexpr int LG = 4;            // lookups per group = the four symbols of one input dword
+    constexpr int NG = ENC_SPT / G;  // merged groups per thread and tile
+    __shared__ __align__(16) uint32_t stg[ENC_STREAM_WINW + 4];
+    __shared__ uint2 s_tab[256 * ENC_REPL];
+    __shared__ __align__(16) uint8_t s_len[256];
+    __shared__ uint32_t s_wave[2][ENC_WAVES];
+    __shared__ uint64_t s_start;
+    __shared__ uint32_t s_la[2], s_have[2];
+
+    const uint32_t batch_lo = p.first_batch + blockIdx.x * p.wg_batches;
+    const uint32_t batch_hi = min(batch_lo + p.wg_batches, p.first_batch + p.n_wg_batches);
+    if (batch_lo >= batch_hi)
+        return;
+    const uint32_t tile_lo = batch_lo * ENC_BATCH, tile_hi = batch_hi * ENC_BATCH;
+    const uint32_t lane = threadIdx.x & 63u;
+    // (the wave's number in a scalar register: what depends on it branches, not masks)
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // A tile's symbols: uniform base + the thread's 32-bit offset.  Nothing
+    // else is loaded from global memory between a request and its use one tile
+    // later (loads complete in order: a younger load that is waited for would
+    // wait for the symbols as well).
+    uint4 ra, rb;
+    auto request = [&](uint32_t tile) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.in + (uint64_t)tile * ENC_TILE);
+        ra = src[threadIdx.x * 2];
+        rb = src[threadIdx.x * 2 + 1];
+    };
+    // the 64 symbols behind a tile, for the wave that completes its last word
+    // (clamped: past the end of the input they are not used)
+    auto request_la = [&](uint32_t tile) -> uint32_t {
+        const uint64_t at = (uint64_t)(tile + 1) * ENC_TILE + lane;
+        return p.in[at < p.n ? at : p.n - 1];
+    };
+    request(tile_lo);
+    uint32_t la_sym = 0, planned = 0;
+    if (wv == (tile_lo & (ENC_WAVES - 1)))
+        la_sym = request_la(tile_lo);
+    enc_stage_table<true>(p, s_tab, s_len);
+    if (threadIdx.x == 0)
+        s_start = p.plan_off[batch_lo / ENC_WAVES] + p.plan_local[batch_lo] + p.lead_bits;
+    for (uint32_t i = threadIdx.x; i < sizeof(stg) / 16; i += ENC_THREADS)
+        reinterpret_cast<uint4 *>(&stg[0])[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    // what is the same in every lane is kept in scalar registers: the vector
+    // registers are needed for the merged groups
+    uint64_t S;
+    {
+        const uint64_t s = s_start;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)s);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(s >> 32));
+        S = (uint64_t)hi << 32 | lo;
+    }
+    uint32_t batch_bits = 0;
+
+#pragma unroll 1
+    for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
+        // ---- 1. one lookup per symbol; merged groups stay in registers
+        uint32_t code[NG], y[PACKED ? 1 : NG], ysum = 0;
+        {
+            const uint32_t raw[ENC_SPT / 4] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            uint2 cur[LG], nxt[LG];
+            auto fetch = [&](uint2 e[LG], int q) {
+#pragma unroll
+                for (int j = 0; j < LG; ++j)
+                    e[j] = s_tab[((raw[q] >> (8 * j)) & 0xffu) * ENC_REPL];
+            };
+            fetch(cur, 0);
+#pragma unroll
+            for (int q = 0; q < ENC_SPT / LG; ++q) {
+                if (q + 1 < ENC_SPT / LG)
+                    fetch(nxt, q + 1);
+#pragma unroll
+                for (int k = 0; k < LG; k += G) {
+                    uint32_t c = cur[k].x, l = cur[k].y; // l = len | len << 27
+#pragma unroll
+                    for (int j = 1; j < G; ++j) {
+                        c = (c << (cur[k + j].y & 31u)) | cur[k + j].x;
+                        l += cur[k + j].y;
+                    }
+                    ysum += l;
+                    if (PACKED)
+                        c |= l & 0xf8000000u;
+                    // (pinned here: left alone, the compiler moves the merging down to
+                    // the packing and keeps all 32 table entries alive until then)
+                    if (PACKED) {
+                        asm volatile("" : "+v"(c));
+                    } else {
+                        asm volatile("" : "+v"(c), "+v"(l));
+                        y[(q * LG + k) / G] = l;
+                    }
+                    code[(q * LG + k) / G] = c;
+                }
+#pragma unroll
+                for (int j = 0; j < LG; ++j)
+                    cur[j] = nxt[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the low 27 bits of the length words collect plain lengths (at most 32 x 31)
+        const uint32_t nbits = ysum & 0x07ffffffu;
+        // ---- 2. bit offsets
+        const uint32_t incl = wave_incl_scan(nbits);
+        if (lane == 63)
+            s_wave[tile & 1u][wv] = incl;
+        // one wave completes the tile's last word in advance
+        if (wv == (tile & (ENC_WAVES - 1))) {
+            if (lane == 0)
+                s_la[tile & 1u] = 0;
+            enc_lookahead_bits(p, (uint64_t)(tile + 1) * ENC_TILE, la_sym, s_tab, &s_la[tile & 1u],
+                               &s_have[tile & 1u]);
+        }
+        const uint32_t planned_now = planned;
+        if (tile + 1 < tile_hi) { // the next tile's symbols travel while this one is packed
+            request(tile + 1);
+            if (wv == ((tile + 1) & (ENC_WAVES - 1)))
+                la_sym = request_la(tile + 1);
+            if (((tile + 1) & (ENC_BATCH - 1)) == ENC_BATCH - 1)
+                planned = p.plan_tot[(tile + 1) / ENC_BATCH];
+        }
+        __syncthreads();
+        uint32_t woff = 0, tile_bits = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < ENC_WAVES; ++i) {
+            const uint32_t x = s_wave[tile & 1u][i];
+            woff += i < wv ? x : 0u;
+            tile_bits += x;
+        }
+        tile_bits = (uint32_t)__builtin_amdgcn_readfirstlane(tile_bits);
+        woff = (uint32_t)__builtin_amdgcn_readfirstlane(woff);
+        const uint32_t toff = woff + incl - nbits;
+        batch_bits += tile_bits;
+        const uint64_t E = S + tile_bits;
+
+        // gap array: bit length of every chunk, start bit of every segment
+        if (p.chunk_bits) {
+            const uint32_t cpt = p.chunk_syms / ENC_SPT; // threads per chunk: 2, 4 or 8
+            const uint32_t wave_end = woff + __shfl(incl, 63, 64);
+            const uint32_t nxt_off = __shfl_down(toff, cpt, 64);
+            const uint32_t b1 = lane + cpt < 64u ? nxt_off : wave_end;
+            if ((threadIdx.x & (cpt - 1)) == 0) {
+                const uint64_t c = (uint64_t)tile * (ENC_THREADS / cpt) + threadIdx.x / cpt;
+                if (c < p.n_chunks) {
+                    p.chunk_bits[c] = (uint16_t)(b1 - toff);
+                    if ((c % HF_SEG_CHUNKS) == 0)
+                        p.seg_off[c / HF_SEG_CHUNKS] = S + toff;
+                }
+            }
+        }
+        if ((tile & (ENC_BATCH - 1)) == ENC_BATCH - 1) {
+            // the batches were placed by their histograms: if a total disagrees,
+            // the histograms belong to other data
+            if (threadIdx.x == 0 && planned_now != batch_bits)
+                atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_PLAN);
+            batch_bits = 0;
+        }
+        if (threadIdx.x == 0 && (uint64_t)(tile + 1) * ENC_TILE == p.n)
+            p.result[HF_RES_TOTAL_BITS] = E - p.lead_bits;
+
+        // ---- 3. and 4.  stream words [g0, g1) belong to this tile; the image
+        // starts at the 16-byte unit of the stream that holds bit S
+        const uint64_t gbase = (S >> 7) << 2;
+        const uint64_t g0 = tile == 0 ? 0 : (S + 31) >> 5;
+        const uint64_t g1 = (E + 31) >> 5;
+        if (g1 > g0) {
+            const uint32_t s_lo = (uint32_t)(S - (gbase << 5)); // 0..127
+            const uint32_t endbit = s_lo + tile_bits;
+            const uint32_t need = (32u - (endbit & 31u)) & 31u;
+            const uint32_t nwords = (uint32_t)(g1 - gbase); // at most ENC_STREAM_WINW
+            if (nbits) {
+                EncSinkCarry<PAD> sink(stg, s_lo + toff);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (PACKED)
+                        sink.append_packed(code[g]);
+                    else
+                        sink.append(code[g], y[g]);
+                }
+                sink.finish();
+            }
+            enc_finish_pass<PAD, ENC_STREAM_WINW>(p, stg, s_la[tile & 1u], s_have[tile & 1u], E, gbase,
+                                                  g0, g1, endbit, need, nwords, 0, false);
+        }
+        S = E;
     }
 }
 

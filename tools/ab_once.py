@@ -1,0 +1,48 @@
+"""A/B of the planned encoder's two kernels on one box: the one-lookup kernel
+(default) against the two-lookup kernel (context option debug = 512), with
+their outputs compared: python tools/ab_once.py [kind ...] [--mib N]"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from huffman_amd import device as hd, synth
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+mib = 1024
+for a in sys.argv[1:]:
+    if a.startswith("--mib="):
+        mib = int(a[6:])
+n = mib << 20
+for kind in args or ["zipf", "testfile"]:
+    data = synth.generate_device(kind, n, seed=2024)
+    plan = hd.new_batch_hist(n, data.device)
+    d_hist = torch.empty(256, dtype=torch.int64, device="cuda")
+    hd.histogram_async(data, d_hist, batch_hist=plan)
+    hist = d_hist.cpu().numpy().astype("uint64")
+    codes, lens = hd.build_codebook(hist)
+    model = hd.DeviceModel(codes, lens)
+    ctx = model.ctx
+    res = {}
+    for rnd in range(2):
+        for dbg in (512, 0):
+            ctx.set_option("debug", dbg)
+            bufs = hd.EncodeBuffers(model, n, 64)
+            ts = []
+            for i in range(25):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                hd.encode_async(data, model, bufs, plan=plan)
+                e1.record()
+                torch.cuda.synchronize()
+                if i >= 5:
+                    ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            print(f"{kind} {mib} MiB debug {dbg:3d}: planned encode median {ts[len(ts) // 2]:.4f} min {ts[0]:.4f} ms",
+                  flush=True)
+            res[dbg] = (bufs.data.clone(), bufs.chunk_bits.clone(), bufs.seg_off.clone(), bufs.result.clone())
+            del bufs
+    same = all(torch.equal(a, b) for a, b in zip(res[0], res[512]))
+    print(f"{kind}: outputs identical: {same}; flags {int(res[0][3][1])}", flush=True)
+    ctx.set_option("debug", 0)
+    del res, data, plan
+    torch.cuda.empty_cache()
