@@ -1169,19 +1169,20 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
             request(tile + 1);
             if (wv == ((tile + 1) & (ENC_WAVES - 1)))
                 la_sym = request_la(tile + 1);
-            if (((tile + 1) & (ENC_BATCH - 1)) == ENC_BATCH - 1)
+            // (by one thread: a value that is the same in all lanes would be moved
+            // to a scalar register at once, and that waits for the symbols)
+            if (threadIdx.x == 0 && ((tile + 1) & (ENC_BATCH - 1)) == ENC_BATCH - 1)
                 planned = p.plan_tot[(tile + 1) / ENC_BATCH];
         }
         __syncthreads();
-        uint32_t woff = 0, tile_bits = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < ENC_WAVES; ++i) {
-            const uint32_t x = s_wave[tile & 1u][i];
-            woff += i < wv ? x : 0u;
-            tile_bits += x;
-        }
-        tile_bits = (uint32_t)__builtin_amdgcn_readfirstlane(tile_bits);
-        woff = (uint32_t)__builtin_amdgcn_readfirstlane(woff);
+        // the eight wave totals, scanned across lanes 0..7 of every wave
+        static_assert(ENC_WAVES == 8, "the scan below covers eight lanes");
+        uint32_t wsum = s_wave[tile & 1u][lane & (ENC_WAVES - 1)];
+        wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x111, 0xf, 0xf, false); // row_shr:1
+        wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x112, 0xf, 0xf, false); // row_shr:2
+        wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x114, 0xf, 0xf, false); // row_shr:4
+        const uint32_t tile_bits = (uint32_t)__builtin_amdgcn_readlane((int)wsum, ENC_WAVES - 1);
+        const uint32_t woff = wv ? (uint32_t)__builtin_amdgcn_readlane((int)wsum, wv - 1) : 0u;
         const uint32_t toff = woff + incl - nbits;
         batch_bits += tile_bits;
         const uint64_t E = S + tile_bits;
@@ -1189,7 +1190,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
         // gap array: bit length of every chunk, start bit of every segment
         if (p.chunk_bits) {
             const uint32_t cpt = p.chunk_syms / ENC_SPT; // threads per chunk: 2, 4 or 8
-            const uint32_t wave_end = woff + __shfl(incl, 63, 64);
+            const uint32_t wave_end = woff + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t nxt_off = __shfl_down(toff, cpt, 64);
             const uint32_t b1 = lane + cpt < 64u ? nxt_off : wave_end;
             if ((threadIdx.x & (cpt - 1)) == 0) {
