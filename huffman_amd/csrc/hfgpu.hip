@@ -908,12 +908,17 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         // complete planned batches of a model for the carry sink: one lookup per symbol
         // (debug bit 512, timing experiments: the two-lookup kernel instead)
         uint32_t grid_wgs = grid;
-        if (planned && lean && carry && model->maxlen <= ENC_STREAM_MAXLEN && !(ctx->debug & 512)) {
-            // merged codes of at most 22 bits travel as one register per group
-            const bool packed = (uint32_t)g * model->maxlen <= 22u;
-            // (two codes of at most ENC_STREAM_MAXLEN bits always are)
-            kern = g == 4 ? (packed ? enc_pack_stream_kernel<4, true> : enc_pack_stream_kernel<4, false>)
-                          : enc_pack_stream_kernel<2, true>;
+        // complete planned batches of a model whose codes have at most
+        // ENC_STREAM_MAXLEN bits: one lookup per symbol, whatever merge width the
+        // model was given for the other kernel (debug bit 512, timing experiments:
+        // that kernel instead)
+        if (planned && lean && model->maxlen <= ENC_STREAM_MAXLEN && !(ctx->debug & 512)) {
+            if (model->maxlen * 4u <= 22u) // merged codes of at most 22 bits: one register per group
+                kern = enc_pack_stream_kernel<4, true>;
+            else if (model->maxlen * 4u <= 31u)
+                kern = enc_pack_stream_kernel<4, false>;
+            else // (two codes of at most ENC_STREAM_MAXLEN bits always are)
+                kern = enc_pack_stream_kernel<2, true>;
             const uint32_t slots = (uint32_t)ctx->num_cus * ENC_STREAM_WGS_PER_CU;
             p.wg_batches = (grid + slots - 1) / slots;
             p.n_wg_batches = grid;

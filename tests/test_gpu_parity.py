@@ -936,3 +936,81 @@ def test_shards_with_lead_bits_concatenate_to_the_whole_stream(dev, orc, kind):
         merged[first:last] |= bufs.data[: last - first].cpu().numpy()
     assert plan.total_bytes == want.size
     assert np.array_equal(merged, want)
+
+
+def _alphabet_data(rng, n, symbols, skew):
+    """n bytes over `symbols` values, probabilities proportional to skew^-rank."""
+    w = skew ** -np.arange(symbols, dtype=np.float64)
+    return rng.choice(symbols, size=n, p=w / w.sum()).astype(np.uint8)
+
+
+@pytest.mark.parametrize("symbols,skew", [(2, 1.0), (16, 1.0), (64, 1.0), (128, 1.0), (256, 1.004),
+                                          (256, 1.01), (200, 1.02), (100, 1.05)])
+def test_planned_encode_of_complete_batches_by_code_length(dev, orc, symbols, skew):
+    """The planned encoder takes complete batches of models whose codes have at
+    most 11 bits through its one-lookup kernel, in three forms by the longest
+    code (four codes per group in one register or in two, two codes per group):
+    every form against the chained encoder and the oracle, with a ragged batch
+    behind the complete ones."""
+    import torch
+
+    rng = np.random.default_rng(symbols * 7 + int(skew * 1000))
+    n = 5 * 65536 + 777
+    host = _alphabet_data(rng, n, symbols, skew)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(host))
+    assert int(np.max(lens)) <= 11
+    want, _ = orc.encode_slice(host, codes, lens)
+    data = to_gpu(host)
+    model = dev.DeviceModel(codes, lens)
+    bh = dev.new_batch_hist(n, data.device)
+    dev.histogram_async(data, batch_hist=bh)
+    planned = dev.EncodeBuffers(model, n, 64)
+    chained = dev.EncodeBuffers(model, n, 64)
+    dev.encode_async(data, model, planned, plan=bh)
+    dev.encode_async(data, model, chained)
+    torch.cuda.synchronize()
+    total = int(np.asarray(lens, dtype=np.uint64)[host].sum())
+    assert planned.result.tolist() == [total, 0, 0, 0]
+    nbytes = (total + 7) // 8
+    assert np.array_equal(planned.data[:nbytes].cpu().numpy(), want)
+    assert torch.equal(planned.chunk_bits, chained.chunk_bits)
+    assert torch.equal(planned.seg_off, chained.seg_off)
+
+
+@pytest.mark.parametrize("cs", [64, 256])
+def test_planned_encode_many_batches_per_workgroup_and_longest_codes(dev, orc, cs):
+    """More complete batches than resident work-groups (a work-group then takes
+    a run of batches), on data that uses a Zipf codebook's 11-bit codes far more
+    often than the codebook expects: stretches of the rarest symbols fill a
+    tile's image to its last word."""
+    import torch
+
+    n = 1100 * 65536 + 12345
+    host = synth.generate_host("zipf", n, seed=77)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(host))
+    longest = int(np.argmax(lens))
+    assert int(lens[longest]) == 11
+    host = host.copy()
+    host[3 * 16384: 5 * 16384] = longest          # two whole tiles of 11-bit codes
+    host[700 * 65536 + 100: 701 * 65536 + 9000] = longest
+    want, _ = orc.encode_slice(host, codes, lens)
+    data = to_gpu(host)
+    model = dev.DeviceModel(codes, lens)
+    bh = dev.new_batch_hist(n, data.device)
+    dev.histogram_async(data, batch_hist=bh)
+    planned = dev.EncodeBuffers(model, n, cs)
+    chained = dev.EncodeBuffers(model, n, cs)
+    dev.encode_async(data, model, planned, plan=bh)
+    dev.encode_async(data, model, chained)
+    torch.cuda.synchronize()
+    total = int(np.asarray(lens, dtype=np.uint64)[host].sum())
+    assert planned.result.tolist() == [total, 0, 0, 0]
+    nbytes = (total + 7) // 8
+    assert np.array_equal(planned.data[:nbytes].cpu().numpy(), want)
+    assert torch.equal(planned.chunk_bits, chained.chunk_bits)
+    assert torch.equal(planned.seg_off, chained.seg_off)
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dres = torch.zeros(4, dtype=torch.int64, device="cuda")
+    dev.decode_async(planned.data, nbytes, model, n, cs, planned.chunk_bits, planned.seg_off, out, dres)
+    torch.cuda.synchronize()
+    assert int(dres[1].item()) == 0 and torch.equal(out, data)
