@@ -279,18 +279,6 @@ struct EncSinkCarry {
                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         w += full ? 1 : 0;
     }
-    // x = code | len << 27: the code bits only add to the junk below bit 27
-    __device__ __forceinline__ void append_packed(uint32_t x)
-    {
-        acc = (acc << (x >> 27)) | (x & 0x07ffffffu);
-        uint32_t next;
-        const bool full = __builtin_add_overflow(nbl, x, &next);
-        nbl = next;
-        if (full)
-            __hip_atomic_fetch_or(enc_slot_ptr<PAD>(stg, w), (uint32_t)(acc >> (nbl >> 27)),
-                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        w += full ? 1 : 0;
-    }
     __device__ __forceinline__ void finish()
     {
         const uint32_t nb = nbl >> 27;
@@ -661,7 +649,7 @@ __device__ __forceinline__ bool enc_lookback(const EncParams &p, uint32_t tile, 
 // Second half of an image pass: complete the tile's last word from the
 // symbols that follow it (last pass only) and copy the pass's words out with
 // coalesced byte-swapped 16-byte stores, clearing the image on the way.
-template <bool PAD, uint32_t WINW = ENC_WINW>
+template <bool PAD>
 __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *stg,
                                                 uint32_t la_bits, uint32_t la_have,
                                                 uint64_t E, uint64_t gbase,
@@ -669,7 +657,7 @@ __device__ __forceinline__ void enc_finish_pass(const EncParams &p, uint32_t *st
                                                 uint32_t need, uint32_t nwords, uint32_t wlo,
                                                 bool reuse)
 {
-    const uint32_t whi = wlo + WINW;
+    const uint32_t whi = wlo + ENC_WINW;
     const bool last_pass = nwords - 1 < whi;
     // the word that holds the tile's last bit is completed by the first `need`
     // bits of what follows the tile
@@ -1039,6 +1027,108 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
 // 22 bits): added to the sink's counter as it is -- the code bits of a tile's
 // groups stay below bit 27 in sum -- at the price of one shift per group to
 // get the length alone; otherwise two registers, code and len | len << 27.
+// The carry sink (EncSinkCarry) for the plain image layout with a pointer to
+// the word being filled instead of its index: no address arithmetic at the OR.
+struct EncSinkPtr {
+    uint32_t *wp;
+    uint32_t nbl; // nb << 27 | junk
+    uint64_t acc;
+    __device__ __forceinline__ EncSinkPtr(uint32_t *stg, uint32_t bitpos)
+        : wp(stg + (bitpos >> 5)), nbl(bitpos << 27), acc(0)
+    {
+    }
+    __device__ __forceinline__ void step(uint32_t y)
+    {
+        uint32_t next;
+        const bool full = __builtin_add_overflow(nbl, y, &next);
+        nbl = next;
+        if (full)
+            __hip_atomic_fetch_or(wp, (uint32_t)(acc >> (nbl >> 27)), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        wp += full ? 1 : 0;
+    }
+    __device__ __forceinline__ void append(uint32_t code, uint32_t y) // y = len | len << 27
+    {
+        acc = (acc << (y & 63u)) | code;
+        step(y);
+    }
+    // x = code | len << 27: the code bits only add to the junk below bit 27
+    __device__ __forceinline__ void append_packed(uint32_t x)
+    {
+        acc = (acc << (x >> 27)) | (x & 0x07ffffffu);
+        step(x);
+    }
+    __device__ __forceinline__ void finish()
+    {
+        const uint32_t nb = nbl >> 27;
+        if (nb)
+            __hip_atomic_fetch_or(wp, (uint32_t)(acc << (32 - nb)), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+// enc_finish_pass for a tile that fits the (plain) image in one pass: the
+// units that lie wholly inside the tile's words, the stream and the buffer --
+// all but the first and the last, as a rule -- are told apart by two 32-bit
+// comparisons with bounds worked out once per tile.
+__device__ __forceinline__ void enc_finish_stream(const EncParams &p, uint32_t *stg, uint32_t la_bits,
+                                                  uint32_t la_have, uint64_t E, uint64_t gbase,
+                                                  uint64_t g0, uint64_t g1, uint32_t endbit,
+                                                  uint32_t need)
+{
+    if (threadIdx.x == 0 && need)
+        __hip_atomic_fetch_or(stg + (endbit >> 5), la_bits >> (32u - need), __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    // the stream ends inside this tile's last word when fewer than `need`
+    // bits follow the tile: only its leading bytes exist then
+    const uint64_t limit = (need && la_have < need) ? (E + la_have + 7) >> 3 : ~0ull;
+    const uint64_t ga = max(g0, gbase);
+    const uint64_t ua = gbase >> 2, ub = (g1 + 3) >> 2;
+    const uint32_t nunits = (uint32_t)(ub - ua);
+    const uint32_t jlo = (uint32_t)((ga - gbase + 3) >> 2);
+    uint32_t jhi = (uint32_t)((g1 - gbase) >> 2);
+    const uint64_t whole = min(limit, p.out_cap) >> 4; // 16-byte units that exist in full
+    if (whole < ub)
+        jhi = whole > ua ? min(jhi, (uint32_t)(whole - ua)) : 0u;
+    if (!p.out_aligned16)
+        jhi = 0;
+    uint4 *dst = reinterpret_cast<uint4 *>(p.out) + ua;
+    uint4 *img = reinterpret_cast<uint4 *>(__builtin_assume_aligned(stg, 16));
+    for (uint32_t j = threadIdx.x; j < nunits; j += ENC_THREADS) {
+        // the thread that copies a unit out also clears it
+        const uint4 v = img[j];
+        img[j] = make_uint4(0, 0, 0, 0);
+        const uint32_t vals[4] = {bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)};
+        if (j >= jlo && j < jhi) {
+            dst[j] = make_uint4(vals[0], vals[1], vals[2], vals[3]);
+        } else {
+            const uint64_t u = ua + j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t g = (u << 2) + q;
+                if (g < ga || g >= g1)
+                    continue;
+                const uint64_t bb = g << 2;
+                if (bb + 4 <= limit && bb + 4 <= p.out_cap) {
+                    *reinterpret_cast<uint32_t *>(p.out + bb) = vals[q];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (bb + i < limit) {
+                            if (bb + i < p.out_cap)
+                                p.out[bb + i] = (uint8_t)(vals[q] >> (8 * i));
+                            else
+                                atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
+                                         (unsigned long long)HF_FLAG_CAPACITY);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Codes of at most ENC_STREAM_MAXLEN bits: a tile's part of the stream always
 // fits the image, so this kernel has no second image pass.
 constexpr uint32_t ENC_STREAM_MAXLEN = 11;
@@ -1051,7 +1141,6 @@ constexpr uint32_t ENC_STREAM_WGS_PER_CU = 4;
 template <int G, bool PACKED>
 __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream_kernel(EncParams p)
 {
-    constexpr bool PAD = false;
     constexpr int LG = 4;            // lookups per group = the four symbols of one input dword
     constexpr int NG = ENC_SPT / G;  // merged groups per thread and tile
     __shared__ __align__(16) uint32_t stg[ENC_STREAM_WINW + 4];
@@ -1221,9 +1310,8 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
             const uint32_t s_lo = (uint32_t)(S - (gbase << 5)); // 0..127
             const uint32_t endbit = s_lo + tile_bits;
             const uint32_t need = (32u - (endbit & 31u)) & 31u;
-            const uint32_t nwords = (uint32_t)(g1 - gbase); // at most ENC_STREAM_WINW
             if (nbits) {
-                EncSinkCarry<PAD> sink(stg, s_lo + toff);
+                EncSinkPtr sink(stg, s_lo + toff);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if (PACKED)
@@ -1233,8 +1321,10 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
                 }
                 sink.finish();
             }
-            enc_finish_pass<PAD, ENC_STREAM_WINW>(p, stg, s_la[tile & 1u], s_have[tile & 1u], E, gbase,
-                                                  g0, g1, endbit, need, nwords, 0, false);
+            // (g1 - gbase words, at most ENC_STREAM_WINW)
+            const uint32_t la_bits = (uint32_t)__builtin_amdgcn_readfirstlane(s_la[tile & 1u]);
+            const uint32_t la_have = (uint32_t)__builtin_amdgcn_readfirstlane(s_have[tile & 1u]);
+            enc_finish_stream(p, stg, la_bits, la_have, E, gbase, g0, g1, endbit, need);
         }
         S = E;
     }
