@@ -252,9 +252,7 @@ def run_workload(args, env, kind: str, n: int, steps: int, warmup: int) -> dict:
     traffic, traffic_source = pmc_traffic(kind, n, cs, dom)
     roofline = {
         "bound": "hbm",
-        "kernel": {"encode": "enc_bytes_kernel" if int(state["lens"].min()) == 8 and maxlen == 8 else
-                   # (planned encode, codes of at most 11 bits: the one-lookup kernel)
-                   "enc_pack_stream_kernel" if maxlen <= 11 and not args.no_plan else "enc_pack_kernel",
+        "kernel": {"encode": ctx.encode_kernel(),
                    # (larger chunks of a model whose table needs a second level take dec_kernel)
                    "decode": "dec_kernel_reg" if cs == 64 or maxlen <= 11 else "dec_kernel"}[dom],
         "achieved": round(kernels[dom]["GBps"], 1),

@@ -53,6 +53,7 @@ extern "C" {
     pub fn hf_last_error(ctx: *const hf_ctx) -> *const c_char;
     pub fn hf_ctx_set_option(ctx: *mut hf_ctx, name: *const c_char, value: i64) -> c_int;
     pub fn hf_ctx_kernel_ms(ctx: *mut hf_ctx, kind: c_int, sum_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn hf_ctx_encode_kernel(ctx: *const hf_ctx) -> *const c_char;
 
     // ---- src/stats.rs
     pub fn hf_histogram_async(ctx: *mut hf_ctx, d_in: *const u8, n: u64, d_hist: *mut u64) -> c_int;

@@ -91,6 +91,7 @@ struct hf_ctx {
     };
     Timed timed[3];
     bool kernel_timing = false;
+    const char *encode_kernel = ""; // what the last encode launched over its complete batches
 };
 
 struct hf_model {
@@ -489,6 +490,8 @@ int hf_ctx_synchronize(hf_ctx *ctx)
     return HF_OK;
 }
 
+const char *hf_ctx_encode_kernel(const hf_ctx *ctx) { return ctx ? ctx->encode_kernel : ""; }
+
 int hf_ctx_kernel_ms(hf_ctx *ctx, int kind, double *sum_ms, uint64_t *launches)
 {
     DeviceGuard on(ctx);
@@ -802,6 +805,7 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spans, (uint64_t)ctx->num_cus * 2));
         const uint32_t cs = d_chunk_bits ? chunk_syms : 64;
         auto kern = enc_bytes_kernel;
+        ctx->encode_kernel = "enc_bytes_kernel";
         if (!fixed_scratch)
             HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE,
                             hipLaunchKernelGGL(kern, dim3(grid), dim3(ENCB_THREADS), 0, ctx->stream,
@@ -840,7 +844,15 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
 #endif
         p.debug &= ~16u; // the phase trace overwrites the tail of the output buffer
 
-    const size_t need = ((size_t)n_tiles + 4) * sizeof(uint64_t);
+    size_t need = ((size_t)n_tiles + 4) * sizeof(uint64_t);
+    // Planned encode of a model with longer codes whose groups of four rarely
+    // exceed 31 bits: the one-lookup kernel, which lists the tiles it cannot
+    // finish for enc_fix_tiles_kernel (16 bytes per tile behind the plan arrays;
+    // not with the fixed scratch block, which is too small for the list)
+    const bool spec_stream = d_batch_hist && !fixed_scratch && model->maxlen > ENC_STREAM_MAXLEN &&
+                             model->enc_group == 4 && !(ctx->debug & 512);
+    if (spec_stream)
+        need += 16 + (size_t)n_tiles * 16;
     void *work = fixed_scratch;
     if (fixed_scratch) {
         if (need > fixed_bytes)
@@ -870,8 +882,14 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         uint64_t *off = static_cast<uint64_t *>(work);
         uint32_t *local = reinterpret_cast<uint32_t *>(off + n_groups + 1);
         uint32_t *tot = local + n_batches;
+        if (spec_stream) {
+            p.fail_count = reinterpret_cast<uint32_t *>(
+                (reinterpret_cast<uintptr_t>(tot + n_batches) + 15) & ~(uintptr_t)15);
+            p.fail_list = p.fail_count + 4;
+        }
         hipLaunchKernelGGL(enc_plan_bits_kernel, dim3(n_groups), dim3(ENC_THREADS), 0, ctx->stream,
-                           d_batch_hist, model->d_len8, off, local, tot, n_batches, d_result);
+                           d_batch_hist, model->d_len8, off, local, tot, n_batches, d_result,
+                           p.fail_count);
         hipLaunchKernelGGL(enc_scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, off,
                            n_groups, d_result);
         p.plan_off = off;
@@ -912,24 +930,33 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         // ENC_STREAM_MAXLEN bits: one lookup per symbol, whatever merge width the
         // model was given for the other kernel (debug bit 512, timing experiments:
         // that kernel instead)
-        if (planned && lean && model->maxlen <= ENC_STREAM_MAXLEN && !(ctx->debug & 512)) {
-            if (model->maxlen * 4u <= 22u) // merged codes of at most 22 bits: one register per group
-                kern = enc_pack_stream_kernel<4, true>;
+        const bool stream = planned && lean && !(ctx->debug & 512) &&
+                            (model->maxlen <= ENC_STREAM_MAXLEN || spec_stream);
+        if (stream) {
+            if (spec_stream)
+                kern = enc_pack_stream_kernel<4, false, true>;
+            else if (model->maxlen * 4u <= 22u) // merged codes of at most 22 bits: one register per group
+                kern = enc_pack_stream_kernel<4, true, false>;
             else if (model->maxlen * 4u <= 31u)
-                kern = enc_pack_stream_kernel<4, false>;
+                kern = enc_pack_stream_kernel<4, false, false>;
             else // (two codes of at most ENC_STREAM_MAXLEN bits always are)
-                kern = enc_pack_stream_kernel<2, true>;
+                kern = enc_pack_stream_kernel<2, true, false>;
             const uint32_t slots = (uint32_t)ctx->num_cus * ENC_STREAM_WGS_PER_CU;
             p.wg_batches = (grid + slots - 1) / slots;
             p.n_wg_batches = grid;
             grid_wgs = (grid + p.wg_batches - 1) / p.wg_batches;
         }
+        if (lean)
+            ctx->encode_kernel = stream ? "enc_pack_stream_kernel" : "enc_pack_kernel";
         // (only the launch over the complete batches is timed: the ragged rest is one workgroup)
         if (lean && !fixed_scratch)
             HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE,
                             hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(ENC_THREADS), 0, ctx->stream, p));
         else
             hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(ENC_THREADS), 0, ctx->stream, p);
+        if (lean && spec_stream && stream) // the tiles the kernel above left out (as a rule: none)
+            hipLaunchKernelGGL(enc_fix_tiles_kernel, dim3(ENC_FIX_GRID), dim3(ENC_THREADS), 0,
+                               ctx->stream, p);
         if (chained && lean) // the follow-up launch numbers its own workgroups from zero again
             p.ticket += 1;
     }

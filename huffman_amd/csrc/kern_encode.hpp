@@ -84,6 +84,10 @@ struct EncParams {
     uint32_t first_batch; // batch index of this launch's first workgroup
     uint32_t wg_batches;   // enc_pack_stream_kernel: consecutive batches per workgroup
     uint32_t n_wg_batches; //   and batches of the launch
+    // enc_pack_stream_kernel on a model with longer codes: tiles it could not
+    // finish, {tile, start bit low, high, -} each, for enc_fix_tiles_kernel
+    uint32_t *fail_list;
+    uint32_t *fail_count;
     uint32_t debug;       // timing experiments only: bit mask of phases to skip
 };
 
@@ -483,11 +487,14 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_tile_bits_kernel(EncParams p)
 // total, which kernel 2 scans: 8 times fewer entries for its single workgroup.
 __global__ __launch_bounds__(ENC_THREADS) void enc_plan_bits_kernel(
     const uint32_t *__restrict__ batch_hist, const uint8_t *__restrict__ len8,
-    uint64_t *group_off, uint32_t *local, uint32_t *tot, uint32_t n_batches, uint64_t *result)
+    uint64_t *group_off, uint32_t *local, uint32_t *tot, uint32_t n_batches, uint64_t *result,
+    uint32_t *fail_count)
 {
     __shared__ uint32_t s_tot[ENC_WAVES];
     if (blockIdx.x == 0 && threadIdx.x < HF_RES_WORDS)
         result[threadIdx.x] = 0; // first kernel of a planned encode: no separate memset
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fail_count)
+        *fail_count = 0;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * ENC_WAVES + wv;
     uint32_t sum = 0; // at most 65536 symbols of at most 57 bits
@@ -1138,9 +1145,10 @@ constexpr uint32_t ENC_STREAM_WINW = ENC_TILE * ENC_STREAM_MAXLEN / 32 + 8;
 // workgroups per CU.
 constexpr int ENC_STREAM_WAVES = 8;  // waves per SIMD
 constexpr uint32_t ENC_STREAM_WGS_PER_CU = 4;
-template <int G, bool PACKED>
+template <int G, bool PACKED, bool SPEC>
 __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream_kernel(EncParams p)
 {
+    static_assert(!(SPEC && PACKED), "groups that may overflow keep their length word");
     constexpr int LG = 4;            // lookups per group = the four symbols of one input dword
     constexpr int NG = ENC_SPT / G;  // merged groups per thread and tile
     __shared__ __align__(16) uint32_t stg[ENC_STREAM_WINW + 4];
@@ -1200,6 +1208,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
         // ---- 1. one lookup per symbol; merged groups stay in registers
         uint32_t code[NG], y[PACKED ? 1 : NG], ysum = 0;
+        uint32_t worst = 0; // SPEC: the largest group length, shifted up by five bits
         {
             const uint32_t raw[ENC_SPT / 4] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
             uint2 cur[LG], nxt[LG];
@@ -1222,6 +1231,8 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
                         l += cur[k + j].y;
                     }
                     ysum += l;
+                    if (SPEC) // lengths and long-code flags sit below bit 27
+                        worst = max(worst, l << 5);
                     if (PACKED)
                         c |= l & 0xf8000000u;
                     // (pinned here: left alone, the compiler moves the merging down to
@@ -1240,12 +1251,18 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the low 27 bits of the length words collect plain lengths (at most 32 x 31)
-        const uint32_t nbits = ysum & 0x07ffffffu;
+        // the low bits of the length words collect plain lengths (at most 32 x 57;
+        // the flags of codes above 32 bits add up from bit 24 on)
+        const uint32_t nbits = ysum & (SPEC ? 0x00ffffffu : 0x07ffffffu);
+        // SPEC: a group of more than 31 bits, or one with a code above 32 bits,
+        // cannot go through the carry sink: the lane writes nothing and the tile
+        // is put on the list for enc_fix_tiles_kernel
+        const bool bad = SPEC && worst > (31u << 5);
         // ---- 2. bit offsets
         const uint32_t incl = wave_incl_scan(nbits);
-        if (lane == 63)
-            s_wave[tile & 1u][wv] = incl;
+        const bool wave_bad = SPEC && __ballot(bad) != 0;
+        if (lane == 63) // (a wave's total stays below 2^17)
+            s_wave[tile & 1u][wv] = incl | (wave_bad ? 0x80000000u : 0u);
         // one wave completes the tile's last word in advance
         if (wv == (tile & (ENC_WAVES - 1))) {
             if (lane == 0)
@@ -1267,6 +1284,9 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
         // the eight wave totals, scanned across lanes 0..7 of every wave
         static_assert(ENC_WAVES == 8, "the scan below covers eight lanes");
         uint32_t wsum = s_wave[tile & 1u][lane & (ENC_WAVES - 1)];
+        const bool any_bad = SPEC && __ballot((wsum >> 31) != 0) != 0;
+        if (SPEC)
+            wsum &= 0x7fffffffu;
         wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x111, 0xf, 0xf, false); // row_shr:1
         wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x112, 0xf, 0xf, false); // row_shr:2
         wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x114, 0xf, 0xf, false); // row_shr:4
@@ -1278,12 +1298,19 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
 
         // gap array: bit length of every chunk, start bit of every segment
         if (p.chunk_bits) {
-            const uint32_t cpt = p.chunk_syms / ENC_SPT; // threads per chunk: 2, 4 or 8
+            // threads per chunk: 2, 4 or 8 (as a shift: a division by a run-time
+            // value is worked out before the loop and its result kept, in scratch
+            // memory in the end, whose reload waits for the symbols)
+            const uint32_t cshift = (uint32_t)__builtin_ctz(p.chunk_syms / ENC_SPT);
+            const uint32_t cpt = 1u << cshift;
             const uint32_t wave_end = woff + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t nxt_off = __shfl_down(toff, cpt, 64);
             const uint32_t b1 = lane + cpt < 64u ? nxt_off : wave_end;
             if ((threadIdx.x & (cpt - 1)) == 0) {
-                const uint64_t c = (uint64_t)tile * (ENC_THREADS / cpt) + threadIdx.x / cpt;
+                uint32_t tid = threadIdx.x; // (opaque: worked out here, per tile, not kept)
+                asm volatile("" : "+v"(tid));
+                const uint64_t c = ((uint64_t)tile << 9 >> cshift) + (tid >> cshift);
+                static_assert(ENC_THREADS == 512, "chunks per tile = 512 >> cshift");
                 if (c < p.n_chunks) {
                     p.chunk_bits[c] = (uint16_t)(b1 - toff);
                     if ((c % HF_SEG_CHUNKS) == 0)
@@ -1306,11 +1333,19 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
         const uint64_t gbase = (S >> 7) << 2;
         const uint64_t g0 = tile == 0 ? 0 : (S + 31) >> 5;
         const uint64_t g1 = (E + 31) >> 5;
-        if (g1 > g0) {
+        // SPEC: more bits than the image holds; nothing of the tile is written here
+        const bool overflow = SPEC && g1 - gbase > ENC_STREAM_WINW;
+        if (SPEC && (any_bad || overflow) && threadIdx.x == 0) {
+            const uint32_t slot = atomicAdd(p.fail_count, 1u);
+            p.fail_list[4 * slot + 0] = tile;
+            p.fail_list[4 * slot + 1] = (uint32_t)S;
+            p.fail_list[4 * slot + 2] = (uint32_t)(S >> 32);
+        }
+        if (g1 > g0 && !overflow) {
             const uint32_t s_lo = (uint32_t)(S - (gbase << 5)); // 0..127
             const uint32_t endbit = s_lo + tile_bits;
             const uint32_t need = (32u - (endbit & 31u)) & 31u;
-            if (nbits) {
+            if (nbits && !bad) {
                 EncSinkPtr sink(stg, s_lo + toff);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
@@ -1327,6 +1362,98 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream
             enc_finish_stream(p, stg, la_bits, la_have, E, gbase, g0, g1, endbit, need);
         }
         S = E;
+    }
+}
+
+
+// Tiles that enc_pack_stream_kernel<.., SPEC> left out (a group of codes above
+// 31 bits, a code above 32 bits, or more bits than its image holds: rare by the
+// choice of that kernel for a model) are encoded again here by the general
+// path: lengths and codes from the 64-bit table in global memory, as many image
+// passes as the tile needs.  Every word the tile owns is written in full, so
+// what the first kernel wrote of it does not matter.  Workgroups beyond the list's
+// length leave at once; the list is empty for most inputs.
+constexpr uint32_t ENC_FIX_GRID = 1024;
+__global__ __launch_bounds__(ENC_THREADS) void enc_fix_tiles_kernel(EncParams p)
+{
+    constexpr bool PAD = false;
+    __shared__ __align__(16) uint32_t stg[ENC_IMG_SLOTS];
+    __shared__ uint2 s_tab[256 * ENC_REPL];
+    __shared__ __align__(16) uint8_t s_len[256];
+    __shared__ uint32_t s_wave[ENC_WAVES];
+    __shared__ uint64_t s_tab64[256]; // code << 6 | len, any length
+    __shared__ uint32_t s_la, s_have;
+    const uint32_t count = *p.fail_count;
+    if (blockIdx.x >= count)
+        return;
+    enc_stage_table<false>(p, s_tab, s_len);
+    if (threadIdx.x < 256)
+        s_tab64[threadIdx.x] = p.tab[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < sizeof(stg) / 16; i += ENC_THREADS)
+        reinterpret_cast<uint4 *>(&stg[0])[i] = make_uint4(0, 0, 0, 0);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t tile = p.fail_list[4 * i];
+        const uint64_t S = (uint64_t)p.fail_list[4 * i + 2] << 32 | p.fail_list[4 * i + 1];
+        const uint64_t base = (uint64_t)tile * ENC_TILE + threadIdx.x * ENC_SPT;
+        const uint64_t tile_end = (uint64_t)(tile + 1) * ENC_TILE;
+        if (threadIdx.x == 0)
+            s_la = 0;
+        __syncthreads(); // tables, image and s_la are ready; the last round is over
+        uint32_t raw[ENC_SPT / 4];
+        enc_load_raw<true>(p, base, ENC_SPT, raw);
+        uint32_t nbits = 0;
+#pragma unroll
+        for (int k = 0; k < ENC_SPT; ++k)
+            nbits += s_len[enc_sym(raw, k)];
+        const uint32_t incl = wave_incl_scan(nbits);
+        if (lane == 63)
+            s_wave[wv] = incl;
+        if (wv == 0) {
+            const uint64_t at = tile_end + lane;
+            enc_lookahead_bits(p, tile_end, p.in[at < p.n ? at : p.n - 1], s_tab, &s_la, &s_have);
+        }
+        __syncthreads();
+        uint32_t woff = 0, tile_bits = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < ENC_WAVES; ++w) {
+            const uint32_t x = s_wave[w];
+            woff += w < wv ? x : 0u;
+            tile_bits += x;
+        }
+        const uint32_t toff = woff + incl - nbits;
+        const uint64_t E = S + tile_bits;
+        const uint64_t gbase = (S >> 7) << 2;
+        const uint64_t g0 = tile == 0 ? 0 : (S + 31) >> 5;
+        const uint64_t g1 = (E + 31) >> 5;
+        if (g1 > g0) {
+            const uint32_t s_lo = (uint32_t)(S - (gbase << 5));
+            const uint32_t endbit = s_lo + tile_bits;
+            const uint32_t need = (32u - (endbit & 31u)) & 31u;
+            const uint32_t nwords = (uint32_t)(g1 - gbase);
+            const uint32_t bitpos = s_lo + toff;
+            for (uint32_t wlo = 0; wlo < nwords; wlo += ENC_WINW) {
+                // the lane's bits that fall into image words [wlo, wlo + ENC_WINW)
+                if (nbits && ((bitpos + nbits - 1) >> 5) >= wlo && (bitpos >> 5) < wlo + ENC_WINW) {
+                    EncSink<PAD> sink(stg, bitpos, wlo);
+#pragma unroll
+                    for (int k = 0; k < ENC_SPT; ++k) {
+                        const uint64_t e = s_tab64[enc_sym(raw, k)];
+                        const uint32_t len = (uint32_t)e & 63u;
+                        const uint64_t code = e >> 6;
+                        if (len > 32) {
+                            sink.append((uint32_t)(code >> 32), len - 32);
+                            sink.append((uint32_t)code, 32);
+                        } else {
+                            sink.append((uint32_t)code, len);
+                        }
+                    }
+                    sink.finish();
+                }
+                enc_finish_pass<PAD>(p, stg, s_la, s_have, E, gbase, g0, g1, endbit, need, nwords, wlo,
+                                     true);
+            }
+        }
     }
 }
 

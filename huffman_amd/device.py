@@ -76,6 +76,10 @@ class Context:
         self.check(lib().hf_ctx_kernel_ms(self.handle, kind, C.byref(ms), C.byref(cnt)))
         return float(ms.value), int(cnt.value)
 
+    def encode_kernel(self) -> str:
+        """Name of the kernel the last encode call launched over its complete batches."""
+        return (lib().hf_ctx_encode_kernel(self.handle) or b"").decode()
+
 
 def _check_u8(t: torch.Tensor) -> torch.Tensor:
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8):

@@ -97,6 +97,11 @@ HF_API int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value);
  * without counterpart in the reference. */
 enum { HF_TIMED_HISTOGRAM = 0, HF_TIMED_ENCODE = 1, HF_TIMED_DECODE = 2 };
 HF_API int hf_ctx_kernel_ms(hf_ctx *ctx, int kind, double *sum_ms, uint64_t *launches);
+/* Name of the kernel the context's last encode call launched over its complete
+ * batches ("enc_pack_stream_kernel", "enc_pack_kernel", "enc_bytes_kernel"; ""
+ * before the first such call): lets a benchmark label the duration above.  A
+ * measuring aid without counterpart in the reference. */
+HF_API const char *hf_ctx_encode_kernel(const hf_ctx *ctx);
 
 /* -------------------------------------------------------- L0: src/stats.rs */
 

@@ -1014,3 +1014,46 @@ def test_planned_encode_many_batches_per_workgroup_and_longest_codes(dev, orc, c
     dev.decode_async(planned.data, nbytes, model, n, cs, planned.chunk_bits, planned.seg_off, out, dres)
     torch.cuda.synchronize()
     assert int(dres[1].item()) == 0 and torch.equal(out, data)
+
+
+@pytest.mark.parametrize("cs", [64, 128])
+def test_planned_encode_long_codes_with_tiles_left_for_the_second_kernel(dev, orc, cs):
+    """A geometric codebook (codes up to about 20 bits at this size, groups of
+    four merged speculatively) on data that breaks its assumptions: stretches of
+    rare symbols make lanes' groups exceed 31 bits, whole tiles of a long code
+    exceed the image, and the one-lookup kernel must hand exactly those tiles to
+    the kernel that follows it.  Stream, gap array and totals against the oracle
+    and the chained encoder."""
+    import torch
+
+    n = 9 * 65536 + 4321
+    host = synth.generate_host("geometric", n, seed=5).copy()
+    codes, lens = orc.generate_extended_codewords(orc.histogram(host))
+    lens_a = np.asarray(lens)
+    assert int(lens_a.max()) > 11
+    rare = int(np.argmax(lens_a))                       # the longest code
+    mid = int(np.flatnonzero(lens_a >= 9)[0])           # four of these exceed 31 bits
+    host[1000:1040] = rare                              # a few lanes of one tile
+    host[70000:70007] = mid
+    host[2 * 65536 + 16384: 2 * 65536 + 3 * 16384] = rare   # two whole tiles: image overflow
+    host[5 * 65536 - 50: 5 * 65536 + 50] = rare         # across a batch boundary
+    host[8 * 65536 + 65000: 9 * 65536 + 100] = mid      # into the ragged batch
+    want, _ = orc.encode_slice(host, codes, lens)
+    data = to_gpu(host)
+    model = dev.DeviceModel(codes, lens)
+    bh = dev.new_batch_hist(n, data.device)
+    dev.histogram_async(data, batch_hist=bh)
+    planned = dev.EncodeBuffers(model, n, cs)
+    chained = dev.EncodeBuffers(model, n, cs)
+    for _ in range(2):  # the second call finds the list of the first one in the scratch block
+        dev.encode_async(data, model, planned, plan=bh)
+    assert model.ctx.encode_kernel() == "enc_pack_stream_kernel"
+    dev.encode_async(data, model, chained)
+    assert model.ctx.encode_kernel() == "enc_pack_kernel"
+    torch.cuda.synchronize()
+    total = int(lens_a.astype(np.uint64)[host].sum())
+    assert planned.result.tolist() == [total, 0, 0, 0]
+    nbytes = (total + 7) // 8
+    assert np.array_equal(planned.data[:nbytes].cpu().numpy(), want)
+    assert torch.equal(planned.chunk_bits, chained.chunk_bits)
+    assert torch.equal(planned.seg_off, chained.seg_off)

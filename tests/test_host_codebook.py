@@ -209,6 +209,7 @@ def test_batch_histogram_size_and_null_context_calls():
     assert L.hf_batch_hist_bytes(1 << 30) == (1 << 30) // 64
     ms, cnt = C.c_double(), C.c_uint64()
     assert L.hf_ctx_kernel_ms(None, 0, C.byref(ms), C.byref(cnt)) == _lib.HF_ERR_BAD_ARG
+    assert L.hf_ctx_encode_kernel(None) == b""
     assert L.hf_histogram_batches_async(None, None, 0, None, None) == _lib.HF_ERR_BAD_ARG
     assert L.hf_encode_planned_async(None, None, None, 0, 0, None, None, 0, 64, None, None,
                                      None) == _lib.HF_ERR_BAD_ARG

@@ -39,7 +39,9 @@ for kind in args or ["zipf", "testfile"]:
             ts.sort()
             print(f"{kind} {mib} MiB debug {dbg:3d}: planned encode median {ts[len(ts) // 2]:.4f} min {ts[0]:.4f} ms",
                   flush=True)
-            res[dbg] = (bufs.data.clone(), bufs.chunk_bits.clone(), bufs.seg_off.clone(), bufs.result.clone())
+            nbytes = (int(bufs.result[0].item()) + 7) // 8  # (the buffer's tail is not written)
+            res[dbg] = (bufs.data[:nbytes].clone(), bufs.chunk_bits.clone(), bufs.seg_off.clone(),
+                        bufs.result.clone())
             del bufs
     same = all(torch.equal(a, b) for a, b in zip(res[0], res[512]))
     print(f"{kind}: outputs identical: {same}; flags {int(res[0][3][1])}", flush=True)
