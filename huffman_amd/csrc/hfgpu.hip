@@ -948,15 +948,21 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         }
         if (lean)
             ctx->encode_kernel = stream ? "enc_pack_stream_kernel" : "enc_pack_kernel";
-        // (only the launch over the complete batches is timed: the ragged rest is one workgroup)
-        if (lean && !fixed_scratch)
-            HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE,
-                            hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(ENC_THREADS), 0, ctx->stream, p));
-        else
+        // (only the launch over the complete batches is timed: the ragged rest is one
+        // workgroup -- together with the kernel that encodes the tiles the speculative
+        // one-lookup kernel left out, as a rule none or a handful: its time belongs to
+        // the encode of the complete batches)
+        const bool fix = lean && spec_stream && stream;
+        auto launch = [&] {
             hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(ENC_THREADS), 0, ctx->stream, p);
-        if (lean && spec_stream && stream) // the tiles the kernel above left out (as a rule: none)
-            hipLaunchKernelGGL(enc_fix_tiles_kernel, dim3(ENC_FIX_GRID), dim3(ENC_THREADS), 0,
-                               ctx->stream, p);
+            if (fix)
+                hipLaunchKernelGGL(enc_fix_tiles_kernel, dim3(ENC_FIX_GRID), dim3(ENC_THREADS), 0,
+                                   ctx->stream, p);
+        };
+        if (lean && !fixed_scratch)
+            HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE, launch());
+        else
+            launch();
         if (chained && lean) // the follow-up launch numbers its own workgroups from zero again
             p.ticket += 1;
     }

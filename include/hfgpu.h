@@ -90,7 +90,8 @@ HF_API const char *hf_last_error(const hf_ctx *ctx);
 HF_API int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value);
 /* With the option "kernel_timing" set, every histogram / encode / decode call
  * brackets its dominant kernel (hist_kernel or hist_batches_kernel, the
- * enc_pack_kernel / enc_pack_stream_kernel launch over the complete batches,
+ * enc_pack_kernel / enc_pack_stream_kernel launch over the complete batches
+ * -- with enc_fix_tiles_kernel behind it where that kernel runs --,
  * the decode kernel) with HIP events on the stream it is launched on.  This waits for the context's
  * stream, returns the summed duration and the number of launches since the
  * last collection (at most 4096 are kept) and starts over.  A measuring aid
