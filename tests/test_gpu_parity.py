@@ -1057,3 +1057,34 @@ def test_planned_encode_long_codes_with_tiles_left_for_the_second_kernel(dev, or
     assert np.array_equal(planned.data[:nbytes].cpu().numpy(), want)
     assert torch.equal(planned.chunk_bits, chained.chunk_bits)
     assert torch.equal(planned.seg_off, chained.seg_off)
+
+
+@pytest.mark.parametrize("kind", ["zipf", "geometric"])
+def test_planned_encode_respects_the_output_capacity(dev, orc, kind):
+    """The planned encoder's kernels for complete batches against a buffer that
+    is exactly large enough, one byte short, and cut at an odd place in the
+    middle: nothing is written at or behind the capacity, what lies before it is
+    the stream, and the flags say that bytes were dropped."""
+    import torch
+
+    n = 6 * 65536 + 99
+    host = synth.generate_host(kind, n, seed=21)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(host))
+    want, _ = orc.encode_slice(host, codes, lens)
+    data = to_gpu(host)
+    model = dev.DeviceModel(codes, lens)
+    bh = dev.new_batch_hist(n, data.device)
+    dev.histogram_async(data, batch_hist=bh)
+    total = int(np.asarray(lens, dtype=np.uint64)[host].sum())
+    for cap in (want.size, want.size - 1, want.size // 2 + 3, 17):
+        bufs = dev.EncodeBuffers(model, n, 64, out_cap=want.size + 4096)
+        bufs.data.fill_(0xAB)
+        bufs.cap = cap
+        dev.encode_async(data, model, bufs, plan=bh)
+        torch.cuda.synchronize()
+        got = bufs.data.cpu().numpy()
+        assert np.array_equal(got[:cap], want[:cap]), cap
+        assert np.all(got[cap:] == 0xAB), cap
+        bits, flags = bufs.result.tolist()[:2]
+        assert bits == total
+        assert flags == (0 if cap == want.size else 1), cap  # HF_FLAG_CAPACITY
