@@ -16,6 +16,12 @@ namespace {
 
 // ------------------------------------------------------------------- encode
 //
+// Two pack kernels share the tile geometry, the image copy-out and the rule of
+// word ownership below: enc_pack_kernel (described first; chained, planned and
+// three-kernel mode, any model, ragged ends) and, further down,
+// enc_pack_stream_kernel (planned mode, complete batches: one lookup per
+// symbol) with enc_fix_tiles_kernel behind its speculative form.
+//
 // A tile is 16384 consecutive symbols: 512 threads x a run of 32 consecutive
 // symbols (two 16-byte loads) each.  A workgroup handles a batch of four tiles.
 //   1. the symbols stay in registers; a byte table of code lengths in LDS
@@ -25,8 +31,8 @@ namespace {
 //   2. start bit of the batch in the stream: either read from a scanned array
 //      (three-kernel mode) or obtained inside the same launch by a chained
 //      scan with decoupled look-back over 8-byte {status,value} descriptors;
-//   3. every thread looks its symbols up in an LDS table of {code, len} pairs
-//      (four replicas, a lane uses replica lane % 4), merges G neighbouring
+//   3. every thread looks its symbols up in an LDS table of {code, len} pairs,
+//      merges G neighbouring
 //      codes, streams them MSB-first through a 64-bit accumulator and ORs
 //      finished 32-bit words into an LDS image of the tile's part of the
 //      stream (the image is aligned to 16-byte units of the stream);
