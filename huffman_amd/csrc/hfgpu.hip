@@ -923,13 +923,12 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
                              : enc_pack_kernel<G, false, false, false>))
         kern = g == 4 ? HF_PICK(4) : (g == 2 ? HF_PICK(2) : HF_PICK(1));
 #undef HF_PICK
-        // complete planned batches of a model for the carry sink: one lookup per symbol
-        // (debug bit 512, timing experiments: the two-lookup kernel instead)
         uint32_t grid_wgs = grid;
         // complete planned batches of a model whose codes have at most
-        // ENC_STREAM_MAXLEN bits: one lookup per symbol, whatever merge width the
-        // model was given for the other kernel (debug bit 512, timing experiments:
-        // that kernel instead)
+        // ENC_STREAM_MAXLEN bits, whatever merge width the model was given for the
+        // other kernel, or of one with longer codes that are merged four at a time:
+        // one lookup per symbol (debug bit 512, timing experiments: the other
+        // kernel instead)
         const bool stream = planned && lean && !(ctx->debug & 512) &&
                             (model->maxlen <= ENC_STREAM_MAXLEN || spec_stream);
         if (stream) {
