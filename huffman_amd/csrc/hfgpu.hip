@@ -845,12 +845,12 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         p.debug &= ~16u; // the phase trace overwrites the tail of the output buffer
 
     size_t need = ((size_t)n_tiles + 4) * sizeof(uint64_t);
-    // Planned encode of a model with longer codes whose groups of four rarely
-    // exceed 31 bits: the one-lookup kernel, which lists the tiles it cannot
-    // finish for enc_fix_tiles_kernel (16 bytes per tile behind the plan arrays;
-    // not with the fixed scratch block, which is too small for the list)
+    // Planned encode of a model with longer codes whose groups of four (or two)
+    // rarely exceed 31 bits: the one-lookup kernel, which lists the tiles it
+    // cannot finish for enc_fix_tiles_kernel (16 bytes per tile behind the plan
+    // arrays; not with the fixed scratch block, which is too small for the list)
     const bool spec_stream = d_batch_hist && !fixed_scratch && model->maxlen > ENC_STREAM_MAXLEN &&
-                             model->enc_group == 4 && !(ctx->debug & 512);
+                             model->enc_group >= 2 && !(ctx->debug & 512);
     if (spec_stream)
         need += 16 + (size_t)n_tiles * 16;
     void *work = fixed_scratch;
@@ -932,15 +932,18 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         const bool stream = planned && lean && !(ctx->debug & 512) &&
                             (model->maxlen <= ENC_STREAM_MAXLEN || spec_stream);
         if (stream) {
-            if (spec_stream)
+            uint32_t per_cu = ENC_STREAM_WGS_PER_CU;
+            if (spec_stream && g == 4)
                 kern = enc_pack_stream_kernel<4, false, true>;
+            else if (spec_stream)
+                kern = enc_pack_stream_kernel<2, false, true>, per_cu = 3;
             else if (model->maxlen * 4u <= 22u) // merged codes of at most 22 bits: one register per group
                 kern = enc_pack_stream_kernel<4, true, false>;
             else if (model->maxlen * 4u <= 31u)
                 kern = enc_pack_stream_kernel<4, false, false>;
             else // (two codes of at most ENC_STREAM_MAXLEN bits always are)
                 kern = enc_pack_stream_kernel<2, true, false>;
-            const uint32_t slots = (uint32_t)ctx->num_cus * ENC_STREAM_WGS_PER_CU;
+            const uint32_t slots = (uint32_t)ctx->num_cus * per_cu;
             p.wg_batches = (grid + slots - 1) / slots;
             p.n_wg_batches = grid;
             grid_wgs = (grid + p.wg_batches - 1) / p.wg_batches;

@@ -1151,8 +1151,12 @@ constexpr uint32_t ENC_STREAM_WINW = ENC_TILE * ENC_STREAM_MAXLEN / 32 + 8;
 // workgroups per CU.
 constexpr int ENC_STREAM_WAVES = 8;  // waves per SIMD
 constexpr uint32_t ENC_STREAM_WGS_PER_CU = 4;
+// (Two codes per group in two registers each -- the speculative form for models
+// that merge two codes at a time -- need 74 registers: three workgroups per CU.)
+template <int G, bool PACKED>
+constexpr int enc_stream_waves = (G == 2 && !PACKED) ? ENC_MIN_WAVES : ENC_STREAM_WAVES;
 template <int G, bool PACKED, bool SPEC>
-__global__ __launch_bounds__(ENC_THREADS, ENC_STREAM_WAVES) void enc_pack_stream_kernel(EncParams p)
+__global__ __launch_bounds__(ENC_THREADS, (enc_stream_waves<G, PACKED>)) void enc_pack_stream_kernel(EncParams p)
 {
     static_assert(!(SPEC && PACKED), "groups that may overflow keep their length word");
     constexpr int LG = 4;            // lookups per group = the four symbols of one input dword

@@ -1088,3 +1088,39 @@ def test_planned_encode_respects_the_output_capacity(dev, orc, kind):
         bits, flags = bufs.result.tolist()[:2]
         assert bits == total
         assert flags == (0 if cap == want.size else 1), cap  # HF_FLAG_CAPACITY
+
+
+@pytest.mark.parametrize("symbols,skew", [(256, 1.02), (256, 1.03), (256, 1.04), (100, 1.15)])
+def test_planned_encode_long_codes_merged_two_at_a_time(dev, orc, symbols, skew):
+    """Models whose codes reach 13 to 19 bits and whose merged pairs stay below 32
+    bits with near certainty: the speculative one-lookup kernel with two codes
+    per group.  Pairs of the longest codes (which the data has, and which a few
+    inserted stretches make frequent) go to the second kernel."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    n = 9 * 65536 + 4321
+    host = _alphabet_data(rng, n, symbols, skew)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(host))
+    lens_a = np.asarray(lens)
+    assert 11 < int(lens_a.max()) <= 32
+    rare = int(np.argmax(lens_a))
+    host[4000:4100] = rare
+    host[3 * 65536 - 7: 3 * 65536 + 9] = rare
+    want, _ = orc.encode_slice(host, codes, lens)
+    data = to_gpu(host)
+    model = dev.DeviceModel(codes, lens)
+    bh = dev.new_batch_hist(n, data.device)
+    dev.histogram_async(data, batch_hist=bh)
+    planned = dev.EncodeBuffers(model, n, 64)
+    chained = dev.EncodeBuffers(model, n, 64)
+    dev.encode_async(data, model, planned, plan=bh)
+    assert model.ctx.encode_kernel() == "enc_pack_stream_kernel"
+    dev.encode_async(data, model, chained)
+    torch.cuda.synchronize()
+    total = int(lens_a.astype(np.uint64)[host].sum())
+    assert planned.result.tolist() == [total, 0, 0, 0]
+    nbytes = (total + 7) // 8
+    assert np.array_equal(planned.data[:nbytes].cpu().numpy(), want)
+    assert torch.equal(planned.chunk_bits, chained.chunk_bits)
+    assert torch.equal(planned.seg_off, chained.seg_off)

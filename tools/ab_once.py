@@ -1,6 +1,7 @@
 """A/B of the planned encoder's two kernels on one box: the one-lookup kernel
 (default) against the two-lookup kernel (context option debug = 512), with
-their outputs compared: python tools/ab_once.py [kind ...] [--mib N]"""
+their outputs compared: python tools/ab_once.py [kind ...] [--mib=N]
+(kind skew<r>: 256 symbols with probabilities proportional to r^-rank)"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -13,7 +14,19 @@ for a in sys.argv[1:]:
         mib = int(a[6:])
 n = mib << 20
 for kind in args or ["zipf", "testfile"]:
-    data = synth.generate_device(kind, n, seed=2024)
+    if kind.startswith("skew"):  # skew<r>: 256 symbols, probabilities proportional to r^-rank
+        import numpy as np
+        w = float(kind[4:]) ** -np.arange(256, dtype=np.float64)
+        cdf = torch.tensor(np.cumsum(w / w.sum()), device="cuda")
+        data = torch.empty(n, dtype=torch.uint8, device="cuda")
+        g = torch.Generator(device="cuda")
+        g.manual_seed(2024)
+        for off in range(0, n, 1 << 26):
+            m = min(1 << 26, n - off)
+            u = torch.rand(m, generator=g, device="cuda", dtype=torch.float64)
+            data[off:off + m] = torch.bucketize(u, cdf, right=True).clamp_(max=255).to(torch.uint8)
+    else:
+        data = synth.generate_device(kind, n, seed=2024)
     plan = hd.new_batch_hist(n, data.device)
     d_hist = torch.empty(256, dtype=torch.int64, device="cuda")
     hd.histogram_async(data, d_hist, batch_hist=plan)
