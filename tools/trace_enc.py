@@ -1,7 +1,9 @@
 """Phase timeline of the encode kernel.  Needs a library built with
 HF_ENC_TRACE=1 python huffman_amd/build.py: under the context option debug=16
 its kernel stamps the wall clock at every phase boundary into the tail of the
-output buffer.  python tools/trace_enc.py [kind] [planned]"""
+output buffer.  python tools/trace_enc.py [kind] [planned]
+(The stamps are in enc_pack_kernel; a planned encode is sent there with debug
+bit 512 instead of to the one-lookup kernel.)"""
 import sys
 import numpy as np
 import torch
@@ -20,7 +22,7 @@ plan = None
 if len(sys.argv) > 2 and sys.argv[2] == "planned":
     plan = hd.new_batch_hist(n, data.device)
     hd.histogram_async(data, batch_hist=plan)
-ctx.set_option("debug", 16)
+ctx.set_option("debug", 16 | 512)
 for _ in range(3):
     hd.encode_async(data, model, bufs, plan=plan)
 torch.cuda.synchronize()
