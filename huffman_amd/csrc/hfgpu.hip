@@ -932,19 +932,22 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         const bool stream = planned && lean && !(ctx->debug & 512) &&
                             (model->maxlen <= ENC_STREAM_MAXLEN || spec_stream);
         if (stream) {
-            uint32_t per_cu = ENC_STREAM_WGS_PER_CU;
             if (spec_stream && g == 4)
                 kern = enc_pack_stream_kernel<4, false, true>;
             else if (spec_stream)
-                kern = enc_pack_stream_kernel<2, false, true>, per_cu = 3;
+                kern = enc_pack_stream_kernel<2, false, true>;
             else if (model->maxlen * 4u <= 22u) // merged codes of at most 22 bits: one register per group
                 kern = enc_pack_stream_kernel<4, true, false>;
             else if (model->maxlen * 4u <= 31u)
                 kern = enc_pack_stream_kernel<4, false, false>;
             else // (two codes of at most ENC_STREAM_MAXLEN bits always are)
                 kern = enc_pack_stream_kernel<2, true, false>;
-            const uint32_t slots = (uint32_t)ctx->num_cus * per_cu;
-            p.wg_batches = (grid + slots - 1) / slots;
+            // Batches per workgroup: one, or two for the largest inputs.  Short runs
+            // keep the workgroups that are resident together on neighbouring parts of
+            // the input and of the stream and let the hardware balance the load: runs
+            // that spread the batches over 3 or 4 workgroups per CU from the start (16
+            // batches each at 1 GiB, 256 at 16 GiB) were 7 to 10 % slower.
+            p.wg_batches = grid >= 65536u ? 2u : 1u;
             p.n_wg_batches = grid;
             grid_wgs = (grid + p.wg_batches - 1) / p.wg_batches;
         }

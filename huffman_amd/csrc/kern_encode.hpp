@@ -1018,9 +1018,10 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_MIN_WAVES) void enc_pack_kernel(En
 // enc_pack_kernel reads the length table for the scan and the {code, len}
 // table again for the packing, because a chained batch must publish its bit
 // total before it packs anything, and it requests a whole batch of symbols in
-// one burst and then computes for several times as long.  A planned run of
-// batches knows its start bit beforehand, so a workgroup takes a contiguous
-// run of tiles (p.wg_batches batches) one tile after the other:
+// one burst and then computes for several times as long.  A planned batch
+// knows its start bit beforehand, so a workgroup takes its tiles (those of
+// p.wg_batches consecutive batches: one or two, see the launch) one after the
+// other:
 //   1. look the tile's symbols up, merge G codes at a time and keep the merged
 //      groups in registers; the length words also add up to the thread's bit
 //      total;
@@ -1150,7 +1151,6 @@ constexpr uint32_t ENC_STREAM_WINW = ENC_TILE * ENC_STREAM_MAXLEN / 32 + 8;
 // tile's copy-out and the next packing.  25 KB of LDS and 64 registers: four
 // workgroups per CU.
 constexpr int ENC_STREAM_WAVES = 8;  // waves per SIMD
-constexpr uint32_t ENC_STREAM_WGS_PER_CU = 4;
 // (Two codes per group in two registers each -- the speculative form for models
 // that merge two codes at a time -- need 74 registers: three workgroups per CU.)
 template <int G, bool PACKED>
