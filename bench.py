@@ -253,8 +253,7 @@ def run_workload(args, env, kind: str, n: int, steps: int, warmup: int) -> dict:
     roofline = {
         "bound": "hbm",
         "kernel": {"encode": ctx.encode_kernel(),
-                   # (larger chunks of a model whose table needs a second level take dec_kernel)
-                   "decode": "dec_kernel_reg" if cs == 64 or maxlen <= 11 else "dec_kernel"}[dom],
+                   "decode": ctx.decode_kernel()}[dom],
         "achieved": round(kernels[dom]["GBps"], 1),
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",

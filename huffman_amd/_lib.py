@@ -44,6 +44,7 @@ SIGNATURES = {
     "hf_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "hf_ctx_kernel_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), u64p]),
     "hf_ctx_encode_kernel": (C.c_char_p, [C.c_void_p]),
+    "hf_ctx_decode_kernel": (C.c_char_p, [C.c_void_p]),
     "hf_histogram_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "hf_histogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
     "hf_batch_hist_bytes": (C.c_uint64, [C.c_uint64]),

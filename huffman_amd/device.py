@@ -80,6 +80,10 @@ class Context:
         """Name of the kernel the last encode call launched over its complete batches."""
         return (lib().hf_ctx_encode_kernel(self.handle) or b"").decode()
 
+    def decode_kernel(self) -> str:
+        """Name of the kernel the last decode call launched."""
+        return (lib().hf_ctx_decode_kernel(self.handle) or b"").decode()
+
 
 def _check_u8(t: torch.Tensor) -> torch.Tensor:
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8):

@@ -1,0 +1,152 @@
+"""GPU parity tests of the decoder that takes several symbols per table look-up
+(dec_kernel_quad; the reference's slice decoder is src/huffman/decode/mod.rs:167-231).
+Everything goes through the C ABI and is compared bit for bit with the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from huffman_amd import synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (there is no CPU fallback)")
+    from huffman_amd import device
+
+    return device
+
+
+def to_gpu(a: np.ndarray):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+class forced_table:
+    """Models created inside get the several-symbols table whatever its yield."""
+
+    def __init__(self, dev):
+        self.ctx = dev.Context.get(torch.device("cuda", torch.cuda.current_device()))
+
+    def __enter__(self):
+        self.ctx.set_option("debug", 2048)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        self.ctx.set_option("debug", 0)
+
+
+def roundtrip(dev, orc, data, codes, lens, *, oracle_decode=True, expect_kernel=True):
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    out = dev.decode(enc, model).cpu().numpy()
+    if expect_kernel:  # (a single symbol is no complete prefix code)
+        assert model.ctx.decode_kernel() == "dec_kernel_quad"
+    assert np.array_equal(out, data)
+    if oracle_decode:
+        stream = enc.stream().cpu().numpy()
+        assert np.array_equal(out, orc.decode_read(stream, codes, lens, data.size))
+    return model, enc
+
+
+@pytest.mark.parametrize("kind", ["geometric", "testfile"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 16383, 16384, 16385, 32769, 300007, (1 << 20) + 77])
+def test_steep_streams_take_the_kernel_and_match_the_oracle(dev, orc, kind, n):
+    data = synth.generate_host(kind, n, seed=41 + n)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    roundtrip(dev, orc, data, codes, lens, expect_kernel=len(np.unique(data)) >= 2)
+
+
+@pytest.mark.parametrize("kind", ["zipf", "uniform", "testfile", "geometric"])
+def test_any_complete_prefix_code_through_the_table(dev, orc, kind):
+    # one symbol per look-up (uniform), one to two (Zipf): the table is not worth
+    # having there, but it must decode them all the same
+    n = 777777
+    data = synth.generate_host(kind, n, seed=5)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    with forced_table(dev):
+        roundtrip(dev, orc, data, codes, lens)
+
+
+@pytest.mark.parametrize("nsym,growth", [(34, 2.0), (20, 2.3), (48, 1.7), (57, 1.62), (12, 3.0)])
+def test_long_codes_leave_through_the_multi_level_table(dev, orc, nsym, growth):
+    """Counts that grow like growth^k: code lengths 1 .. nsym - 1, most of them
+    longer than the table's index.  The data uses the long codes far more often
+    than the model expects, so many look-ups find no symbol in the index and go
+    through the sub-tables (and, past 32 bits, the key search)."""
+    hist = np.zeros(256, dtype=np.uint64)
+    hist[100: 100 + nsym] = np.maximum(1, growth ** np.arange(nsym)[::-1]).astype(np.uint64)
+    codes, lens = orc.generate_extended_codewords(hist)
+    assert int(lens.max()) <= 57
+    rng = np.random.default_rng(nsym)
+    n = 200003
+    w = np.full(nsym, 1.0)
+    w[: nsym // 2] = 4.0
+    data = (100 + rng.choice(nsym, size=n, p=w / w.sum())).astype(np.uint8)
+    with forced_table(dev):
+        roundtrip(dev, orc, data, codes, lens)
+    # and with data that follows the model (short codes dominate)
+    p = hist[100: 100 + nsym].astype(np.float64)
+    data = (100 + rng.choice(nsym, size=n, p=p / p.sum())).astype(np.uint8)
+    with forced_table(dev):
+        roundtrip(dev, orc, data, codes, lens)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_models_and_sizes(dev, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    nsym = int(rng.integers(2, 200))
+    steep = float(rng.uniform(1.0, 2.5))
+    hist = np.zeros(256, dtype=np.uint64)
+    syms = rng.permutation(256)[:nsym]
+    hist[syms] = np.maximum(1, steep ** rng.uniform(0, min(40, 56 / np.log2(max(steep, 1.0001))), nsym)).astype(np.uint64)
+    codes, lens = orc.generate_extended_codewords(hist)
+    if int(lens.max()) > 57:
+        pytest.skip("codes above 57 bits are refused")
+    n = int(rng.integers(1, 400000))
+    p = hist[syms].astype(np.float64) ** float(rng.uniform(0.3, 1.0))
+    data = syms[rng.choice(nsym, size=n, p=p / p.sum())].astype(np.uint8)
+    with forced_table(dev):
+        roundtrip(dev, orc, data, codes, lens)
+
+
+@pytest.mark.parametrize("in_off,out_off", [(0, 1), (4, 0), (12, 7), (0, 16)])
+def test_buffers_at_odd_addresses(dev, orc, in_off, out_off):
+    n = 150000
+    data = synth.generate_host("geometric", n, seed=9)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    nc, ns = dev.gap_layout(n, 64)
+    # the stream moved to an address that is 4- but not 16-byte aligned, the output anywhere
+    moved = torch.zeros(enc.nbytes + 64, dtype=torch.uint8, device="cuda")
+    moved[in_off: in_off + enc.nbytes] = enc.data[: enc.nbytes]
+    out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    res = torch.zeros(4, dtype=torch.int64, device="cuda")
+    dev.decode_async(moved[in_off:], enc.nbytes, model, n, 64, enc.chunk_bits, enc.seg_off, out[out_off:], res)
+    torch.cuda.synchronize()
+    assert int(res[1]) == 0
+    assert model.ctx.decode_kernel() == "dec_kernel_quad"
+    assert np.array_equal(out[out_off: out_off + n].cpu().numpy(), data)
+    assert int(out[out_off + n:].max()) == 0 and int(out[:out_off].sum()) == 0
+
+
+def test_many_segments_per_cu_and_an_odd_segment_count(dev, orc):
+    # 2^25 + a bit symbols: 2049 segments (an odd number: the last work-group has one
+    # idle half), eight work-groups per CU one after the other
+    n = (1 << 25) + 16384 + 100
+    t = synth.generate_device("geometric", n, seed=3)
+    hist = dev.histogram(t)
+    codes, lens = dev.build_codebook(hist)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(t, model)
+    out = dev.decode(enc, model)
+    assert model.ctx.decode_kernel() == "dec_kernel_quad"
+    assert torch.equal(out, t)
+    # the head and the tail bit for bit against the oracle's decoder
+    head = 1 << 20
+    stream = enc.stream()[: head].cpu().numpy()
+    want = orc.decode_read(stream, codes, lens, head // 2)
+    assert np.array_equal(out[: head // 2].cpu().numpy(), want[: head // 2])

@@ -9,7 +9,9 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 cs = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+debug = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # the library's "debug" option (kernel choices)
 n = mib << 20
+hd.Context.get("cuda").set_option("debug", debug)
 data = synth.generate_device(kind, n, seed=2024)
 hist = hd.histogram(data)
 codes, lens = hd.build_codebook(hist)

@@ -40,7 +40,7 @@ print("kernel span us:", (tr[:, :, 7].max() - tr[:, :, 0].min()) / 100.0)
 life = (a[:, 7] - a[:, 0]) / 100.0
 print("WG lifetime us: mean %.2f median %.2f p10 %.2f p90 %.2f" % (life.mean(), np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
 spans = [(0, 1, "gap array+table+scan"), (1, 2, "stage stream image"), (2, 3, "barrier"),
-         (3, 4, "decode the chunk"), (4, 7, "transpose + store")]
+         (3, 4, "decode the chunk"), (4, 7, "transpose + store (dec_kernel_quad: barrier, rows out)")]
 sel = slice(4000, n_seg - 2000)
 for who, x in (("thread 0 (wave 0)", a), ("thread 192 (wave 3)", b)):
     print(who)
