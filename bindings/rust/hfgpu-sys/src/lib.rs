@@ -54,6 +54,7 @@ extern "C" {
     pub fn hf_ctx_set_option(ctx: *mut hf_ctx, name: *const c_char, value: i64) -> c_int;
     pub fn hf_ctx_kernel_ms(ctx: *mut hf_ctx, kind: c_int, sum_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn hf_ctx_encode_kernel(ctx: *const hf_ctx) -> *const c_char;
+    pub fn hf_ctx_decode_kernel(ctx: *const hf_ctx) -> *const c_char;
 
     // ---- src/stats.rs
     pub fn hf_histogram_async(ctx: *mut hf_ctx, d_in: *const u8, n: u64, d_hist: *mut u64) -> c_int;
@@ -110,6 +111,8 @@ extern "C" {
     pub fn hf_build_gap_array(ctx: *mut hf_ctx, model: *const hf_model, d_in: *const u8, in_bytes: u64,
                               n_out: u64, chunk_syms: u32, d_chunk_bits: *mut u16,
                               d_seg_off: *mut u64) -> c_int;
+    pub fn hf_decode_bare(ctx: *mut hf_ctx, model: *const hf_model, d_in: *const u8, in_bytes: u64,
+                          n_out: u64, d_out: *mut u8) -> c_int;
 
     // ---- one stream over several GPUs
     pub fn hf_shard_plan(hists: *const u64, lens: *const u64, world: u32, bits: *mut u64,

@@ -83,6 +83,7 @@ SIGNATURES = {
                             C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hf_decode_serial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                    C.c_uint64, C.c_void_p]),
+    "hf_decode_bare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "hf_build_gap_array": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                      C.c_uint32, C.c_void_p, C.c_void_p]),
     "hf_shard_plan": (C.c_int, [u64p, u64p, C.c_uint32, u64p, u64p, C.POINTER(C.c_uint32), u64p,

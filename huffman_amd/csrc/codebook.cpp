@@ -438,10 +438,12 @@ uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t
     double c[66] = {0};
     c[0] = 1.0;
     const uint32_t widths[4] = {16u, 8u, 7u, 6u};
-    // a chunk in ten million may hold an overflowing group of 16 or 8 codes, one
-    // in a hundred thousand a group of 7 or 6 (the gain per window is smaller,
-    // but so is the work that a lane which has to decode again repeats)
-    const double limit[4] = {1e-7, 1e-7, 1e-5, 1e-5};
+    // A chunk in ten thousand may hold a group that overflows its window: the
+    // lane decodes its chunk again through global memory and its wave waits for
+    // it, a few thousand instruction slots -- per wave (64 chunks) that is 0.6 %
+    // of a few thousand, against the dozen instructions and three LDS reads
+    // that every window rebuild costs every chunk.
+    const double limit[4] = {1e-4, 1e-4, 1e-4, 1e-4};
     double over[4] = {1.0, 1.0, 1.0, 1.0};
     int lo = 0, hi = 0; // sums that can occur so far (below the overflow bin)
     int minlen = 64, maxl = 0;
@@ -463,7 +465,7 @@ uint32_t pick_decode_window(const uint64_t *keys, const uint8_t *klens, uint64_t
                 over[t] = c[65];
         // more codes overflow at least as often: once the most lenient test
         // fails for this many codes, nothing wider can pass
-        if (i >= 6 && 1.0 - std::pow(1.0 - c[65], 64.0 / i) > 1e-5)
+        if (i >= 6 && 1.0 - std::pow(1.0 - c[65], 64.0 / i) > 1e-4)
             break;
     }
     for (int t = 0; t < 4; ++t) {

@@ -50,6 +50,8 @@ struct hf_ctx {
     hipStream_t scratch_stream = nullptr;
     bool scratch_busy = false;
     uint64_t *d_result = nullptr; // result block of the synchronous entry points
+    uint64_t *h_small = nullptr;  // 8 pinned words: where small results land (a copy into pageable
+                                  // memory goes through the runtime's staging buffer and costs tens of microseconds)
     void *fixed_scratch = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress)
     int num_cus = 256;
     int enc_mode = 1;
@@ -445,10 +447,17 @@ int hf_ctx_create(int device, hf_ctx **out)
         delete ctx;
         return HF_ERR_HIP;
     }
+    e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_small), 8 * sizeof(uint64_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipFree(ctx->d_result);
+        delete ctx;
+        return HF_ERR_HIP;
+    }
     // this device's address of the fixed scratch block (the device is current here)
     e = hipGetSymbolAddress(&ctx->fixed_scratch, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !ctx->fixed_scratch) {
         (void)hipFree(ctx->d_result);
+        (void)hipHostFree(ctx->h_small);
         delete ctx;
         return HF_ERR_HIP;
     }
@@ -487,6 +496,8 @@ int hf_ctx_destroy(hf_ctx *ctx)
     }
     if (ctx->d_result)
         (void)hipFree(ctx->d_result);
+    if (ctx->h_small)
+        (void)hipHostFree(ctx->h_small);
     delete ctx;
     return HF_OK;
 }
@@ -1320,7 +1331,8 @@ int hf_decode_serial(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, ui
 
 namespace {
 
-// hf_build_gap_array, and the same for a window of a longer stream.
+// hf_build_gap_array, the same for a window of a longer stream, and either
+// with the symbols decoded in the last walk.
 //   first_start  bit of d_in[0] at which the first code starts (0..255)
 //   bit_base     stream bit of bit 0 of d_in[0]: the segment offsets are absolute
 //   whole        the window reaches the end of the stream: n_want symbols are
@@ -1329,25 +1341,57 @@ namespace {
 //                the next window (they may run past its end), and as many
 //                whole segments as the rest holds, at most n_want symbols,
 //                are laid out; *n_done receives that count (possibly 0).
+//   d_chunk_bits, d_seg_off   receive the gap array, or both null: none wanted
+//   d_out        receives the symbols, or null: none wanted
 //   *end_bit     bit (from bit 0 of d_in[0]) behind the last of those symbols
 int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
               uint32_t first_start, uint64_t bit_base, bool whole, uint64_t n_want,
-              uint32_t chunk_syms, uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint64_t *n_done,
-              uint64_t *end_bit)
+              uint32_t chunk_syms, uint16_t *d_chunk_bits, uint64_t *d_seg_off, uint8_t *d_out,
+              uint64_t *n_done, uint64_t *end_bit)
 {
     GapParams g{};
-    // d.out is not written; any non-null value passes the shared argument checks
+    const bool gaps = d_chunk_bits != nullptr;
+    // (d.out is only written when d_out is given; any non-null value passes the shared
+    // argument checks)
     int rc = fill_dec_params(ctx, model, d_in, in_bytes, 0, n_want,
-                             reinterpret_cast<uint8_t *>(d_chunk_bits), ctx->d_result, &g.d);
+                             d_out ? d_out : reinterpret_cast<uint8_t *>(ctx->d_result),
+                             ctx->d_result, &g.d);
     if (rc != HF_OK)
         return rc;
     if (in_bytes == 0 || in_bytes >= (1ull << 58))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: empty or oversized stream");
     g.d.chunk_syms = chunk_syms;
-    g.per_window = std::max(1u, 64u / std::max(1u, g.d.sentinel));
+    // Codes taken from one 64-bit window without a look at the bounds: what a window
+    // always holds (64 / sentinel), or -- complete prefix codes only -- what it nearly
+    // always holds under the model's own code lengths (the decoder's speculative window
+    // width): steps that took more are caught and done again.  The sum of a window's
+    // lengths must fit a byte.  And whether the table has entries that need more than
+    // the first level.
+    g.safe_w = std::max(1u, 64u / std::max(1u, g.d.sentinel));
+    uint32_t per_window = g.safe_w;
+    if (model->dec_spec_k > per_window)
+        per_window = std::min<uint32_t>(model->dec_spec_k, 8u);
+    while (per_window > g.safe_w && per_window * g.d.sentinel > 255u)
+        --per_window;
+    const bool esc = model->lut_escapes;
+    struct GapKernels {
+        void (*sync)(GapParams);
+        void (*emit)(GapParams);
+        void (*decode)(GapParams);
+    };
+#define HF_GAP_KERNELS(W, E) GapKernels{gap_sync_kernel<W, E>, gap_emit_kernel<W, E>, gap_decode_kernel<W, E>}
+    const GapKernels kern =
+        per_window >= 8 ? (esc ? HF_GAP_KERNELS(8, true) : HF_GAP_KERNELS(8, false))
+        : per_window >= 6 ? (esc ? HF_GAP_KERNELS(6, true) : HF_GAP_KERNELS(6, false))
+        : per_window >= 5 ? (esc ? HF_GAP_KERNELS(5, true) : HF_GAP_KERNELS(5, false))
+        : per_window >= 4 ? HF_GAP_KERNELS(4, true)
+        : per_window >= 3 ? HF_GAP_KERNELS(3, true)
+        : per_window >= 2 ? HF_GAP_KERNELS(2, true)
+                          : HF_GAP_KERNELS(1, true);
+#undef HF_GAP_KERNELS
     g.total_bits = in_bytes * 8;
     g.n_sub = (g.total_bits + GAP_SUB_BITS - 1) / GAP_SUB_BITS;
-    g.n_wg = (g.n_sub + GAP_THREADS - 1) / GAP_THREADS;
+    g.n_wg = (g.n_sub + GAP_OWN - 1) / GAP_OWN;
     g.n_chunks = (n_want + chunk_syms - 1) / chunk_syms; // (upper bound until n_out is known)
     g.chunk_bits = d_chunk_bits;
     g.seg_off = d_seg_off;
@@ -1365,7 +1409,7 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
     };
     const size_t o_start = take(g.n_sub), o_exit = take(g.n_sub), o_cnt = take(g.n_sub * 4);
     const size_t o_in = take(g.n_wg * 4), o_used = take(g.n_wg * 4), o_chg = take(4);
-    const size_t o_base = take((g.n_wg + 1) * 8), o_s32 = take((g.n_chunks + 1) * 4);
+    const size_t o_base = take((g.n_wg + 1) * 8), o_s32 = take(gaps ? (g.n_chunks + 1) * 4 : 4);
     rc = scratch_acquire(ctx, off);
     if (rc != HF_OK)
         return rc;
@@ -1379,49 +1423,76 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
     g.wg_base = reinterpret_cast<uint64_t *>(b + o_base);
     g.start32 = reinterpret_cast<uint32_t *>(b + o_s32);
     HF_HIP(ctx, hipMemsetAsync(ctx->d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
-    HF_HIP(ctx, hipMemsetAsync(g.exit_off, 0, g.n_sub, ctx->stream));
-    HF_HIP(ctx, hipMemsetAsync(g.wg_used, 0xff, g.n_wg * 4, ctx->stream));
 
     const uint32_t lut_bytes = (g.d.lut_entries * 2u + 15u) & ~15u;
     const size_t lds = lut_bytes + (size_t)GAP_IMG_SLOTS * 4 + GAP_THREADS * 4;
     const dim3 wgs((uint32_t)g.n_wg), one_per_wg((uint32_t)((g.n_wg + GAP_THREADS - 1) / GAP_THREADS));
-    // every round fixes at least the first workgroup whose first start was
-    // wrong, so n_wg + 1 rounds always suffice; real streams need two or three
-    uint64_t round = 0;
-    for (;; ++round) {
+    auto last_walk = [&]() { // gap array and / or symbols from the final starts
+        if (gaps) {
+            hipLaunchKernelGGL(kern.emit, wgs, dim3(GAP_THREADS), lds, ctx->stream, g);
+            hipLaunchKernelGGL(gap_diff_kernel,
+                               dim3((uint32_t)((g.n_chunks + GAP_THREADS - 1) / GAP_THREADS)),
+                               dim3(GAP_THREADS), 0, ctx->stream, g);
+        }
+        if (d_out)
+            HF_TIMED_LAUNCH(ctx, HF_TIMED_DECODE,
+                            hipLaunchKernelGGL(kern.decode, wgs, dim3(GAP_THREADS), lds, ctx->stream, g));
+    };
+    // The first launch lets every work-group assume its first start (from a walk
+    // of its predecessor's last sub-sequence); the check behind it finds those that
+    // assumed wrong, and they run again with the value their predecessor computed.
+    // Every round fixes at least the first work-group whose first start was wrong,
+    // so n_wg + 1 rounds always suffice; real streams need none or one.  For a whole
+    // stream the sums and the last walk are queued behind the check at once and the
+    // host looks at everything together: when the check fails (rarely) they run again.
+    g.first = 1;
+    uint64_t total_syms = 0;
+    uint64_t res[HF_RES_WORDS] = {0};
+    for (uint64_t round = 0;; ++round) {
         if (round > g.n_wg + 1)
             return fail(ctx, HF_ERR_INTERNAL, "hf_build_gap_array: no fixed point");
-        HF_HIP(ctx, hipMemsetAsync(g.changed, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(gap_snapshot_kernel, one_per_wg, dim3(GAP_THREADS), 0, ctx->stream, g);
-        uint32_t changed = 0;
-        HF_HIP(ctx, hipMemcpyAsync(&changed, g.changed, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (!changed)
-            break;
-        g.first = round == 0;
-        hipLaunchKernelGGL(gap_sync_kernel, wgs, dim3(GAP_THREADS), lds, ctx->stream, g);
+        hipLaunchKernelGGL(kern.sync, wgs, dim3(GAP_THREADS), lds, ctx->stream, g);
         HF_HIP(ctx, hipGetLastError());
+        g.first = 0;
+        HF_HIP(ctx, hipMemsetAsync(g.changed, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(gap_verify_kernel, one_per_wg, dim3(GAP_THREADS), 0, ctx->stream, g);
+        hipLaunchKernelGGL(gap_wgsum_kernel, wgs, dim3(GAP_THREADS), 0, ctx->stream, g);
+        hipLaunchKernelGGL(gap_scan_kernel, dim3(1), dim3(GAP_THREADS), 0, ctx->stream, g);
+        uint64_t *h = ctx->h_small; // [0..3] result block, [4] changed, [5] symbols in the stream
+        if (whole) {
+            HF_HIP(ctx, hipMemsetAsync(ctx->d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
+            last_walk();
+            HF_HIP(ctx, hipMemcpyAsync(h, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        h[4] = 0;
+        HF_HIP(ctx, hipMemcpyAsync(h + 4, g.changed, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(ctx, hipMemcpyAsync(h + 5, g.wg_base + g.n_wg, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(res, h, sizeof(res));
+        total_syms = h[5];
+        if (!(uint32_t)h[4])
+            break;
     }
-    hipLaunchKernelGGL(gap_wgsum_kernel, wgs, dim3(GAP_THREADS), 0, ctx->stream, g);
-    hipLaunchKernelGGL(gap_scan_kernel, dim3(1), dim3(GAP_THREADS), 0, ctx->stream, g);
-    uint64_t total_syms = 0;
-    HF_HIP(ctx, hipMemcpyAsync(&total_syms, g.wg_base + g.n_wg, 8, hipMemcpyDeviceToHost,
-                               ctx->stream));
+    HF_HIP(ctx, hipGetLastError());
     uint64_t n_out = n_want;
     if (whole) {
-        HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->scratch_busy = false;
         if (total_syms < n_want)
             return fail(ctx, HF_ERR_DECODE,
                         "hf_build_gap_array: the stream holds %llu symbols, fewer than n_out = %llu",
                         (unsigned long long)total_syms, (unsigned long long)n_want);
-    } else {
+        *n_done = n_out;
+        *end_bit = res[HF_RES_END_BIT];
+        return flags_to_status(ctx, res[HF_RES_FLAGS]);
+    }
+    {
         // symbols whose code starts before the window's last two sub-sequences
         uint64_t safe = 0;
         if (g.total_bits >= 4 * (uint64_t)GAP_SUB_BITS) {
             const uint64_t j_lim = g.total_bits / GAP_SUB_BITS - 2; // first sub-sequence left out
-            const uint64_t wg = j_lim / GAP_THREADS;
+            const uint64_t wg = j_lim / GAP_OWN;
             uint32_t cnt[GAP_THREADS];
-            const uint64_t first_sub = wg * GAP_THREADS, n_cnt = j_lim - first_sub;
+            const uint64_t first_sub = wg * GAP_OWN, n_cnt = j_lim - first_sub;
             HF_HIP(ctx, hipMemcpyAsync(&safe, g.wg_base + wg, 8, hipMemcpyDeviceToHost, ctx->stream));
             if (n_cnt)
                 HF_HIP(ctx, hipMemcpyAsync(cnt, g.cnt + first_sub, n_cnt * 4, hipMemcpyDeviceToHost,
@@ -1429,8 +1500,6 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
             HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (uint64_t i = 0; i < n_cnt; ++i)
                 safe += cnt[i];
-        } else {
-            HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         const uint64_t seg_syms = (uint64_t)HF_SEG_CHUNKS * chunk_syms;
         n_out = std::min(n_want, safe) / seg_syms * seg_syms;
@@ -1443,11 +1512,8 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
     }
     g.d.n_out = n_out;
     g.n_chunks = (n_out + chunk_syms - 1) / chunk_syms;
-    hipLaunchKernelGGL(gap_emit_kernel, wgs, dim3(GAP_THREADS), lds, ctx->stream, g);
-    hipLaunchKernelGGL(gap_diff_kernel, dim3((uint32_t)((g.n_chunks + GAP_THREADS - 1) / GAP_THREADS)),
-                       dim3(GAP_THREADS), 0, ctx->stream, g);
+    last_walk();
     HF_HIP(ctx, hipGetLastError());
-    uint64_t res[HF_RES_WORDS];
     HF_HIP(ctx, hipMemcpyAsync(res, ctx->d_result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->scratch_busy = false;
@@ -1476,7 +1542,24 @@ int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, 
     }
     uint64_t n_done = 0, end_bit = 0;
     return gap_build(ctx, model, d_in, in_bytes, 0, 0, true, n_out, chunk_syms, d_chunk_bits,
-                     d_seg_off, &n_done, &end_bit);
+                     d_seg_off, nullptr, &n_done, &end_bit);
+}
+
+int hf_decode_bare(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t in_bytes,
+                   uint64_t n_out, uint8_t *d_out)
+{
+    DeviceGuard on(ctx);
+    if (!ctx)
+        return HF_ERR_BAD_ARG;
+    if (n_out && !d_out)
+        return fail(ctx, HF_ERR_BAD_ARG, "hf_decode_bare: null output");
+    if (n_out == 0) {
+        DecParams unused{};
+        return fill_dec_params(ctx, model, d_in, in_bytes, 0, 0, nullptr, ctx->d_result, &unused);
+    }
+    uint64_t n_done = 0, end_bit = 0;
+    return gap_build(ctx, model, d_in, in_bytes, 0, 0, true, n_out, 64, nullptr, nullptr, d_out,
+                     &n_done, &end_bit);
 }
 
 // ------------------------------------------------------- host-buffer forms
@@ -1872,9 +1955,12 @@ int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
         HF_HIP(ctx, hipMemcpyAsync(a, h_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     uint16_t *d_cb = reinterpret_cast<uint16_t *>(a + off_cb);
     uint64_t *d_so = reinterpret_cast<uint64_t *>(a + off_so);
-    bool serial = false;
+    bool serial = false, decoded = false;
     if (rebuild) {
-        rc = in_bytes ? hf_build_gap_array(ctx, model, a, in_bytes, n_out, chunk_syms, d_cb, d_so)
+        // the walks that would rebuild the side metadata write the symbols themselves
+        uint64_t n_done = 0, end_bit = 0;
+        rc = in_bytes ? gap_build(ctx, model, a, in_bytes, 0, 0, true, n_out, chunk_syms, nullptr,
+                                  nullptr, a + off_out, &n_done, &end_bit)
                       : HF_ERR_DECODE;
         // a stream that ends early is continued with zero bits, as the reference's
         // drain loop does (src/huffman/decode/mod.rs:219-229): the sequential walk
@@ -1882,6 +1968,8 @@ int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
             serial = true;
         else if (rc != HF_OK)
             return rc;
+        else
+            decoded = true;
     } else if (n_chunks) {
         HF_HIP(ctx, hipMemcpyAsync(d_cb, h_chunk_bits, n_chunks * 2, hipMemcpyHostToDevice,
                                    ctx->stream));
@@ -1894,7 +1982,7 @@ int hf_decode_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_in, uint
         return decode_host_pieces(ctx, model, h_in, in_bytes, n_out, chunk_syms, h_seg_off, d_cb,
                                   d_so, a, a + off_out, h_out, piece_segs, pieces,
                                   reinterpret_cast<uint64_t *>(a + off_res));
-    else if (n_out)
+    else if (n_out && !decoded)
         rc = hf_decode(ctx, model, a, in_bytes, 0, n_out, chunk_syms, d_cb, d_so, a + off_out);
     if (rc != HF_OK)
         return rc;
@@ -1956,23 +2044,17 @@ int hf_decode_window_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_w
     *end_bit = start_bit;
     if (n_max == 0)
         return HF_OK;
-    const uint32_t cs = 64;
-    uint64_t n_chunks = 0, n_segs = 0;
-    hf_gap_layout(n_max, cs, &n_chunks, &n_segs);
+    const uint32_t cs = 64; // (whole segments of 64-symbol chunks are what a window hands over)
     const size_t off_out = align_up(win_bytes + 16, 256);
-    const size_t off_cb = align_up(off_out + n_max + 16, 256);
-    const size_t off_so = align_up(off_cb + n_chunks * 2 + 16, 256);
-    int rc = ensure_arena(ctx, off_so + n_segs * 8 + 16);
+    int rc = ensure_arena(ctx, off_out + n_max + 16);
     if (rc != HF_OK)
         return rc;
     uint8_t *a = static_cast<uint8_t *>(ctx->arena);
     if (win_bytes)
         HF_HIP(ctx, hipMemcpyAsync(a, h_win, win_bytes, hipMemcpyHostToDevice, ctx->stream));
-    uint16_t *d_cb = reinterpret_cast<uint16_t *>(a + off_cb);
-    uint64_t *d_so = reinterpret_cast<uint64_t *>(a + off_so);
     uint64_t n = 0, end = start_bit;
-    rc = win_bytes ? gap_build(ctx, model, a, win_bytes, start_bit, 0, last != 0, n_max, cs, d_cb,
-                               d_so, &n, &end)
+    rc = win_bytes ? gap_build(ctx, model, a, win_bytes, start_bit, 0, last != 0, n_max, cs, nullptr,
+                               nullptr, a + off_out, &n, &end)
                    : HF_ERR_DECODE;
     if (rc == HF_ERR_DECODE && last && n_max <= HF_WRITE_VALUE_MAX && start_bit == 0) {
         // the stream ends early: it is continued with zero bits, as the reference's
@@ -1984,10 +2066,6 @@ int hf_decode_window_host(hf_ctx *ctx, const hf_model *model, const uint8_t *h_w
         end = win_bytes * 8;
     } else if (rc != HF_OK) {
         return rc;
-    } else if (n) {
-        rc = hf_decode(ctx, model, a, win_bytes, 0, n, cs, d_cb, d_so, a + off_out);
-        if (rc != HF_OK)
-            return rc;
     }
     if (n)
         HF_HIP(ctx, hipMemcpyAsync(h_out, a + off_out, n, hipMemcpyDeviceToHost, ctx->stream));

@@ -316,6 +316,18 @@ def decode_serial(data: torch.Tensor, in_bytes: int, model: DeviceModel, n_out: 
     return out
 
 
+def decode_bare(data: torch.Tensor, in_bytes: int, model: DeviceModel, n_out: int,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    """decode::read of a stream without gap array (synchronous)."""
+    ctx = model.ctx
+    ctx.bind_stream()
+    if out is None:
+        out = torch.empty(n_out, dtype=torch.uint8, device=ctx.device)
+    ctx.check(lib().hf_decode_bare(ctx.handle, model.handle, data.data_ptr(), in_bytes, n_out,
+                                   out.data_ptr()))
+    return out
+
+
 def build_gap_array(data: torch.Tensor, in_bytes: int, model: DeviceModel, n_out: int,
                     chunk_syms: int = DEFAULT_CHUNK_SYMS) -> tuple[torch.Tensor, torch.Tensor]:
     """Gap array (chunk_bits, seg_off) of a stream that came without one; the

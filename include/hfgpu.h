@@ -288,6 +288,16 @@ HF_API int hf_build_gap_array(hf_ctx *ctx, const hf_model *model, const uint8_t 
                               uint64_t in_bytes, uint64_t n_out, uint32_t chunk_syms,
                               uint16_t *d_chunk_bits, uint64_t *d_seg_off);
 
+/* decode::read (src/huffman/decode/mod.rs:167-231) of a stream that came
+ * without gap array, device buffers: the walks that hf_build_gap_array makes
+ * write the symbols themselves in their last pass, so neither a gap array nor
+ * a second kernel is needed.  What every decoder of a reference-written file
+ * runs (Decoder::from_header, src/huffman/decode/mod.rs:48-66, and the CLI's
+ * `d`; hf_decode_host without gap arrays calls the same code).  Synchronous.
+ * d_in 4-byte aligned.  Errors as hf_build_gap_array. */
+HF_API int hf_decode_bare(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in,
+                          uint64_t in_bytes, uint64_t n_out, uint8_t *d_out);
+
 /* ------------------------------------------------ one stream over several GPUs
  *
  * The reference encodes one slice in one process (Huffman::from_slice,

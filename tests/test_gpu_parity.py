@@ -508,6 +508,8 @@ def test_build_gap_array_matches_the_encoders(dev, orc, kind, n):
     assert torch.equal(so[:ns], enc.seg_off[:ns])
     bare = dev.Encoded(enc.data, enc.total_bits, 0, n, 64, cb, so)
     assert np.array_equal(dev.decode(bare, model).cpu().numpy(), data)
+    # the same walks with the symbols written in the last one: no gap array at all
+    assert np.array_equal(dev.decode_bare(enc.data, enc.nbytes, model, n).cpu().numpy(), data)
 
 
 @pytest.mark.parametrize("chunk_syms", [128, 256])
@@ -545,6 +547,7 @@ def test_build_gap_array_model_that_is_not_prefix_free(dev, orc):
     bare = dev.Encoded(t, stream.size * 8, 0, n_out, 64, cb, so)
     assert np.array_equal(dev.decode(bare, model).cpu().numpy(), want)
     assert np.array_equal(dev.decode_serial(t, stream.size, model, n_out).cpu().numpy(), want)
+    assert np.array_equal(dev.decode_bare(t, stream.size, model, n_out).cpu().numpy(), want)
 
 
 def test_build_gap_array_long_codes(dev, orc):
@@ -557,6 +560,7 @@ def test_build_gap_array_long_codes(dev, orc):
     nc, ns = dev.gap_layout(data.size, 64)
     assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
     assert torch.equal(so[:ns], enc.seg_off[:ns])
+    assert np.array_equal(dev.decode_bare(enc.data, enc.nbytes, model, data.size).cpu().numpy(), data)
 
 
 def test_build_gap_array_stream_too_short(dev, orc):
@@ -566,6 +570,9 @@ def test_build_gap_array_stream_too_short(dev, orc):
     enc = dev.encode(to_gpu(data), model)
     with pytest.raises(dev.HfError) as ei:
         dev.build_gap_array(enc.data, enc.nbytes // 2, model, data.size)
+    assert ei.value.status == dev._lib.HF_ERR_DECODE
+    with pytest.raises(dev.HfError) as ei:
+        dev.decode_bare(enc.data, enc.nbytes // 2, model, data.size)
     assert ei.value.status == dev._lib.HF_ERR_DECODE
 
 
@@ -579,6 +586,46 @@ def test_build_gap_array_256mib_property(dev):
     nc, ns = dev.gap_layout(n, 64)
     assert torch.equal(cb[:nc], enc.chunk_bits[:nc])
     assert torch.equal(so[:ns], enc.seg_off[:ns])
+    assert torch.equal(dev.decode_bare(enc.data, enc.nbytes, model, n), data)
+
+
+@pytest.mark.parametrize("kind,n", [("geometric", (1 << 28) + 12345), ("uniform", 1 << 27),
+                                    ("testfile", (1 << 27) + 1)])
+def test_decode_bare_large_streams(dev, kind, n):
+    # many work-groups: every one assumes its first start from a walk of its
+    # predecessor's last sub-sequence, and the check behind the launch has to agree
+    data = synth.generate_device(kind, n, seed=78)
+    codes, lens = dev.build_codebook(dev.histogram(data))
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(data, model)
+    out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    dev.decode_bare(enc.data, enc.nbytes, model, n, out[3: 3 + n])  # (output at an odd address)
+    assert torch.equal(out[3: 3 + n], data)
+    assert int(out[:3].sum()) == 0 and int(out[3 + n:].sum()) == 0
+
+
+def test_decode_bare_stream_that_resynchronises_late(dev, orc):
+    """A fixed-length code never resynchronises: a walk that starts at a wrong
+    offset stays wrong to the end of its sub-sequence.  13-bit codes do not divide
+    the 1024-bit sub-sequences, so the assumed starts (offset 0, and the probes at
+    the sub-sequences' ends) are wrong nearly everywhere, and only the repeated
+    rounds -- inside the work-groups and across them -- reach the sequential decode."""
+    codes = np.zeros(256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint64)
+    rng = np.random.default_rng(5)
+    syms = rng.permutation(256)[:200]
+    for i, s in enumerate(syms):
+        codes[s], lens[s] = i * 40, 13
+    n = 600001
+    data = syms[rng.integers(0, len(syms), size=n)].astype(np.uint8)
+    model = dev.DeviceModel(codes, lens)
+    enc = dev.encode(to_gpu(data), model)
+    want, _ = orc.encode_slice(data, codes, lens)
+    assert np.array_equal(enc.stream().cpu().numpy(), want)
+    assert np.array_equal(dev.decode_bare(enc.data, enc.nbytes, model, n).cpu().numpy(), data)
+    cb, so = dev.build_gap_array(enc.data, enc.nbytes, model, n)
+    nc, ns = dev.gap_layout(n, 64)
+    assert torch.equal(cb[:nc], enc.chunk_bits[:nc]) and torch.equal(so[:ns], enc.seg_off[:ns])
 
 
 # ----------------------------------- the benchmark configurations, full size

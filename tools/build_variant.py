@@ -14,10 +14,10 @@ common = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-un
 obj = f"tools/_trace/{name}.o"
 subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "--offload-arch=gfx950", *common, *inc, "-c",
                        "huffman_amd/csrc/hfgpu.hip", "-o", obj])
-if not os.path.exists("huffman_amd/csrc/codebook.o"):
-    subprocess.check_call(["g++", *common, *inc, "-c", "huffman_amd/csrc/codebook.cpp", "-o",
-                           "huffman_amd/csrc/codebook.o"])
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj,
-                       "huffman_amd/csrc/codebook.o", "-o", f"tools/_trace/lib_{name}.so"])
+host_obj = f"tools/_trace/{name}_codebook.o"
+subprocess.check_call(["g++", *common, *inc, "-c", "huffman_amd/csrc/codebook.cpp", "-o", host_obj])
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj, host_obj, "-o",
+                       f"tools/_trace/lib_{name}.so"])
 os.remove(obj)
+os.remove(host_obj)
 print(f"tools/_trace/lib_{name}.so")

@@ -2,7 +2,11 @@
 import sys
 import numpy as np
 import torch
+import os
 sys.path.insert(0, ".")
+from huffman_amd import _lib
+if os.environ.get("HF_TOOLS_LIB"):  # another build of the library, kept beside the production one
+    _lib.LIB_PATH = os.path.abspath(os.environ["HF_TOOLS_LIB"])
 from huffman_amd import device as hd, synth
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
@@ -28,4 +32,4 @@ for _ in range(iters):
     hd.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
 torch.cuda.synchronize()
 assert torch.equal(out, data)
-print("ok", kind, mib, cs)
+print("ok", kind, mib, cs, hd.Context.get("cuda").decode_kernel())

@@ -15,6 +15,8 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 n = mib << 20
+if os.environ.get("HF_TOOLS_DEBUG"):  # the library's "debug" option (kernel choices), set before the model exists
+    hd.Context.get("cuda").set_option("debug", int(os.environ["HF_TOOLS_DEBUG"]))
 data = synth.generate_device(kind, n, seed=2024)
 hist = hd.histogram(data)
 codes, lens = hd.build_codebook(hist)
