@@ -346,34 +346,6 @@ bool build_pair_lut(const DecodeLut &lut, double max_slow, std::vector<uint32_t>
     return slow <= slow_limit;
 }
 
-double build_quad_lut(const DecodeLut &lut, std::vector<uint64_t> *quad)
-{
-    const uint32_t w = HF_QUAD_W, n = 1u << w;
-    quad->assign(n, 0);
-    if (lut.w1 == 0 || lut.w1 > w)
-        return 0.0;
-    uint64_t symbols = 0;
-    for (uint32_t x = 0; x < n; ++x) {
-        uint32_t used = 0, cnt = 0, syms = 0;
-        while (cnt < 4 && used < w) {
-            // the bits behind the codes taken so far, zero filled: a code that ends
-            // inside the index is resolved by the first level whatever the fill
-            const uint32_t rest = (x << used) & (n - 1);
-            const uint16_t e = lut.pool[rest >> (w - lut.w1)];
-            const uint32_t l = HF_LUT_LEN(e);
-            if ((e & HF_LUT_ESC) || l == 0 || used + l > w)
-                break;
-            syms |= HF_LUT_SYM(e) << (24 - 8 * cnt);
-            used += l;
-            ++cnt;
-        }
-        if (cnt)
-            (*quad)[x] = (uint64_t)syms | (uint64_t)(used | cnt << 8) << 32;
-        symbols += cnt;
-    }
-    return (double)symbols / (double)n;
-}
-
 bool prefer_padded_image(double mean_bits, double sd_bits)
 {
     if (!(mean_bits > 0))

@@ -107,8 +107,6 @@ struct hf_model {
     uint16_t *d_lut = nullptr;
     uint32_t *d_pair = nullptr;  // two-symbol table (only when pair_entries != 0)
     uint32_t pair_entries = 0;
-    uint64_t *d_quad = nullptr;  // up to four symbols per look-up (only when quad_yield != 0)
-    double quad_yield = 0;       // symbols an index of that table holds on average
     uint64_t *d_keys = nullptr;
     uint8_t *d_ksyms = nullptr;
     uint8_t *d_klens = nullptr;
@@ -257,17 +255,7 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     if (lut.w1 >= 6 && complete)
         (void)hf::build_pair_lut(lut, 0.01, &pair);
     const size_t off_pair = align_up(off_klens + 256, 16);
-    // table of up to four symbols per look-up: complete prefix codes whose indices
-    // hold two symbols or more on average (steep codes: the short ones dominate)
-    std::vector<uint64_t> quad;
-    double quad_yield = 0;
-    if (complete && m >= 2) {
-        quad_yield = hf::build_quad_lut(lut, &quad);
-        if (quad_yield < 2.0 && !(ctx->debug & 2048))
-            quad.clear(), quad_yield = 0;
-    }
-    const size_t off_quad = align_up(off_pair + pair.size() * sizeof(uint32_t), 16);
-    const size_t total = off_quad + quad.size() * sizeof(uint64_t);
+    const size_t total = off_pair + pair.size() * sizeof(uint32_t);
     hf_ctx::Pinned &ps = ctx->pinned[ctx->pinned_next++ % 4];
     if (ps.used)
         HF_HIP(ctx, hipEventSynchronize(ps.done)); // the copy that last read this buffer is over
@@ -294,8 +282,6 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     std::memcpy(blob + off_klens, klens, m);
     if (!pair.empty())
         std::memcpy(blob + off_pair, pair.data(), pair.size() * sizeof(uint32_t));
-    if (!quad.empty())
-        std::memcpy(blob + off_quad, quad.data(), quad.size() * sizeof(uint64_t));
     for (size_t i = 0; i < ctx->blob_cache.size(); ++i) {
         if (ctx->blob_cache[i].bytes >= total) {
             // kernels of the block's previous owner may still be running: on
@@ -327,8 +313,6 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     mod->d_klens = b + off_klens;
     mod->d_pair = pair.empty() ? nullptr : reinterpret_cast<uint32_t *>(b + off_pair);
     mod->pair_entries = (uint32_t)pair.size();
-    mod->d_quad = quad.empty() ? nullptr : reinterpret_cast<uint64_t *>(b + off_quad);
-    mod->quad_yield = quad_yield;
     mod->lut_entries = (uint32_t)lut.pool.size();
     mod->m = (uint32_t)m;
     mod->sentinel = lut.sentinel;
@@ -559,7 +543,7 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
         ctx->kernel_timing = value != 0;
     else if (!std::strcmp(name, "dec_trace")) // device address, 128 bytes per segment; 0 = off
         ctx->dec_trace = reinterpret_cast<uint64_t *>((uintptr_t)value);
-    else if (!std::strcmp(name, "debug") && value >= 0 && value < 8192)
+    else if (!std::strcmp(name, "debug") && value >= 0 && value < 1024)
         ctx->debug = (int)value;
     else
         return fail(ctx, HF_ERR_BAD_ARG, "unknown option or value out of range: %s", name);
@@ -1256,26 +1240,8 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
             kern = spr == 4 ? dec_kernel<4, false>
                             : (spr == 2 ? dec_kernel<2, false> : dec_kernel<1, false>);
     }
-    // several symbols per look-up: 64-symbol chunks of a model that has the table
-    uint32_t grid = (uint32_t)n_segs, threads = DEC_THREADS;
+    const uint32_t grid = (uint32_t)n_segs, threads = DEC_THREADS;
     ctx->decode_kernel = p.img_cap ? (pairs ? "dec_kernel_reg (pairs)" : "dec_kernel_reg") : "dec_kernel";
-    // (that kernel addresses LDS by plain offsets from 0: it must not have static LDS in front
-    // of its dynamic block)
-    static const int quad_static_lds = [] {
-        hipFuncAttributes a{};
-        return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(dec_kernel_quad)) == hipSuccess
-                   ? (int)a.sharedSizeBytes
-                   : -1;
-    }();
-    if (chunk_syms == 64 && model->d_quad && p.img_cap && quad_static_lds == 0 && !(ctx->debug & 1024)) {
-        ctx->decode_kernel = "dec_kernel_quad";
-        p.quad = model->d_quad;
-        p.istg_words = (p.img_cap + 4u + 3u) & ~3u; // plain image, 16-byte units
-        lds = DECQ_QUAD_BYTES + lut_bytes + 2 * ((size_t)p.istg_words * 4 + HF_SEG_CHUNKS * DECQ_ROW) + 32;
-        kern = dec_kernel_quad;
-        grid = (uint32_t)((n_segs + 1) / 2);
-        threads = DECQ_THREADS;
-    }
     if (lds > 160 * 1024 - 64)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: chunk_syms %u needs %zu bytes of LDS",
                     chunk_syms, lds);

@@ -85,17 +85,6 @@ bool is_complete_prefix_code(const uint64_t *keys, const uint8_t *klens, uint64_
 #define HF_PAIR_SLOW 0x80000000u
 #define HF_PAIR_UNRESOLVED 0x40000000u
 bool build_pair_lut(const DecodeLut &lut, double max_slow, std::vector<uint32_t> *pair);
-// Table of up to four symbols per look-up (complete prefix codes only), indexed
-// by the top HF_QUAD_W bits of the window.  Entry of index x: low word = the
-// symbols of the codes that start at the top of x and end inside its
-// HF_QUAD_W bits, first symbol in the top byte, at most four; high word =
-// their total length | their number << 8.  An index whose first code does not
-// end inside it holds 0: the decoder resolves that code through `lut`.
-// Returns the mean number of symbols per index -- under a well-compressed
-// stream every index is about equally likely, so that is the number of
-// symbols a look-up yields.
-#define HF_QUAD_W 11u
-double build_quad_lut(const DecodeLut &lut, std::vector<uint64_t> *quad);
 // Layout of the decoder's LDS image of the stream.  Lane l of a wave starts
 // reading near word l * mean_bits / 32 (chunk l of the segment), and 32 lanes
 // are served per LDS cycle, one word per bank (word index mod 32): chunk sizes

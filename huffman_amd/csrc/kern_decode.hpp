@@ -52,7 +52,6 @@ struct DecParams {
     uint32_t m;
     const uint32_t *pair;  // two-symbol table over the first-level index (PAIR kernels), or null
     uint32_t pair_entries; // 1 << w1 when pair is set
-    const uint64_t *quad;  // table of up to four symbols per index of HF_QUAD_W bits (dec_kernel_quad), or null
     uint32_t istg_words;   // LDS words reserved for the stream image (padding slots included)
     uint32_t img_cap;      // dec_kernel_reg: stream words the image holds
     uint32_t in_aligned16;
@@ -758,271 +757,6 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                          (unsigned long long)HF_FLAG_DECODE);
         }
     }
-}
-
-// Several symbols per look-up, for complete prefix codes whose short codes
-// dominate (2 bits per symbol and the like).  A table over the top HF_QUAD_W
-// bits of the window holds, per index, every code that ends inside those bits,
-// up to four: the symbols (one per byte), their total length and their number.
-// Each look-up yields a different number of symbols, so the output position
-// is data dependent and the bytes go to a row of the lane's own in LDS: the
-// (up to) four bytes are moved to the row's fill position by a byte funnel
-// shift and OR-ed into its zeroed words, two aligned words per look-up (a
-// 32-bit LDS store at an address that is not a multiple of four is legal on
-// gfx950, but costs eight times an aligned one: tools/ubench/lds_unaligned.hip).  A lane's loop ends when its row holds the chunk's 64 symbols;
-// what a lane appends past that within its last group of look-ups lands in
-// eight spare bytes behind the row.  One window of 64 bits serves five
-// look-ups (5 x HF_QUAD_W <= 64).  An index whose first code is longer than
-// HF_QUAD_W bits holds no symbol: the lane stands still for the rest of its
-// group and resolves that code through the multi-level table at the top of the
-// next one, where the window is whole.  The rows leave through coalesced
-// 16-byte stores after a barrier.  A work-group of 512 lanes decodes two
-// segments and stages the tables once for both.
-constexpr int DECQ_THREADS = 512;
-constexpr uint32_t DECQ_ROW = 76;       // bytes: 64 symbols, 8 spare, a flag word (19 words: rows start on different banks)
-constexpr uint32_t DECQ_ROW_FLAG = 72;  // offset of the word that says "this row holds a whole chunk"
-constexpr uint32_t DECQ_QUAD_BYTES = 8u << HF_QUAD_W;
-// LDS accesses by 32-bit byte offset (no generic pointer, no base to add).
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t lds_load32(uint32_t a)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *(__attribute__((address_space(3))) const uint32_t *)a;
-#else
-    return a;
-#endif
-}
-__device__ __forceinline__ u32x2 lds_load64(uint32_t a)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *(__attribute__((address_space(3))) const u32x2 *)a;
-#else
-    return u32x2{a, a};
-#endif
-}
-__device__ __forceinline__ void lds_or32(uint32_t a, uint32_t v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t *)a, v, __ATOMIC_RELAXED,
-                          __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-
-__global__ __launch_bounds__(DECQ_THREADS) void dec_kernel_quad(DecParams p)
-{
-    extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t lut_bytes = (p.lut_entries * 2u + 15u) & ~15u;
-    const uint32_t half = threadIdx.x >> 8, t = threadIdx.x & 255u;
-    const uint32_t off_lut = DECQ_QUAD_BYTES;
-    const uint32_t off_img = off_lut + lut_bytes + half * p.istg_words * 4u;
-    const uint32_t off_rows_all = off_lut + lut_bytes + 2u * p.istg_words * 4u;
-    const uint32_t off_rows = off_rows_all + half * (HF_SEG_CHUNKS * DECQ_ROW);
-    const uint16_t *s_lut = reinterpret_cast<const uint16_t *>(smem + off_lut);
-    uint32_t *img = reinterpret_cast<uint32_t *>(smem + off_img);
-    uint32_t *s_wave = reinterpret_cast<uint32_t *>(smem + off_rows_all + 2u * HF_SEG_CHUNKS * DECQ_ROW) + half * 4u;
-
-    const uint64_t last_seg = (p.n_chunks - 1) / HF_SEG_CHUNKS;
-    const uint64_t seg_raw = (uint64_t)blockIdx.x * 2u + half;
-    const bool seg_valid = seg_raw <= last_seg;
-    const uint64_t seg = seg_valid ? seg_raw : last_seg;
-    const uint64_t c = seg * HF_SEG_CHUNKS + t;
-    const bool valid = seg_valid && c < p.n_chunks;
-#ifdef HF_DEC_TRACE
-    uint64_t *trp = (p.trace && seg_valid && (t == 0 || t == 192)) ? p.trace + seg * 16 + (t ? 8 : 0) : nullptr;
-#endif
-    DEC_TRACE(0);
-    // everything the set-up needs is requested at once, small answers first
-    const uint32_t cb = valid ? p.chunk_bits[c] : 0u;
-    const uint4 *lut16 = reinterpret_cast<const uint4 *>(p.lut);
-    const uint4 *quad16 = reinterpret_cast<const uint4 *>(p.quad);
-    const uint32_t lut_units = lut_bytes / 16;
-    const uint4 lut0 = lut16[min(threadIdx.x, lut_units - 1u)];
-    const uint4 q0 = quad16[threadIdx.x], q1 = quad16[threadIdx.x + DECQ_THREADS];
-    const uint64_t so0 = p.seg_off[seg], so1 = p.seg_off[min(seg + 1, last_seg)];
-    __builtin_amdgcn_sched_barrier(0);
-    const uint64_t seg_start = so0 - p.bit_base;
-    const uint64_t ubase = seg_start >> 7;
-    const uint32_t s_lo = (uint32_t)(seg_start & 127u);
-    const uint32_t IMG_CAP = p.img_cap;
-    constexpr int EARLY = 4;
-    const uint64_t whole = p.in_bytes >> 4;
-    const uint4 *in16 = reinterpret_cast<const uint4 *>(p.in);
-    uint32_t nunits_e = 0;
-    if (seg_valid && seg < last_seg && p.in_aligned16 && so1 - so0 <= (uint64_t)IMG_CAP * 32u) {
-        nunits_e = (uint32_t)((s_lo + (so1 - so0) + 127u) / 128u) + 1u;
-        if (nunits_e * 4u > IMG_CAP || ubase + nunits_e > whole)
-            nunits_e = 0;
-    }
-    uint4 st[EARLY];
-    {
-        const uint4 *from = nunits_e ? in16 + ubase : lut16;
-        const uint32_t top = nunits_e ? nunits_e - 1u : 0u;
-#pragma unroll
-        for (int k = 0; k < EARLY; ++k)
-            st[k] = from[min(t + k * HF_SEG_CHUNKS, top)];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        uint4 *qdst = reinterpret_cast<uint4 *>(smem);
-        qdst[threadIdx.x] = q0;
-        qdst[threadIdx.x + DECQ_THREADS] = q1;
-        uint4 *ldst = reinterpret_cast<uint4 *>(smem + off_lut);
-        if (threadIdx.x < lut_units)
-            ldst[threadIdx.x] = lut0;
-        for (uint32_t i = threadIdx.x + DECQ_THREADS; i < lut_units; i += DECQ_THREADS)
-            ldst[i] = lut16[i];
-        // the rows start out zero: symbols are OR-ed into them
-        uint4 *rdst = reinterpret_cast<uint4 *>(smem + off_rows_all);
-        constexpr uint32_t ROW_UNITS = 2u * HF_SEG_CHUNKS * DECQ_ROW / 16u;
-        for (uint32_t i = threadIdx.x; i < ROW_UNITS; i += DECQ_THREADS)
-            rdst[i] = make_uint4(0, 0, 0, 0);
-    }
-    // chunk offsets: scan over the 256 lanes of this half
-    uint32_t total, excl;
-    {
-        const uint32_t incl = wave_incl_scan(cb);
-        const uint32_t lane = threadIdx.x & 63u, wv = (threadIdx.x >> 6) & 3u;
-        if (lane == 63)
-            s_wave[wv] = incl;
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-            const uint32_t x = s_wave[i];
-            woff += i < wv ? x : 0u;
-            tot += x;
-        }
-        total = tot;
-        excl = woff + incl - cb;
-    }
-    DEC_TRACE(1);
-    const uint32_t nunits = (s_lo + total + 127u) / 128u + 1u; // +1: readers run ahead
-    const bool use_lds = seg_valid && nunits * 4u <= IMG_CAP && p.in_aligned16;
-    if (use_lds) {
-        const bool early_ok = nunits <= nunits_e;
-        if (early_ok) {
-#pragma unroll
-            for (int k = 0; k < EARLY; ++k) {
-                const uint32_t i = t + k * HF_SEG_CHUNKS;
-                if (i < nunits) {
-                    uint4 v = st[k];
-                    v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
-                    reinterpret_cast<uint4 *>(img)[i] = v;
-                }
-            }
-        }
-        for (uint32_t i = t + (early_ok ? EARLY * HF_SEG_CHUNKS : 0); i < nunits; i += HF_SEG_CHUNKS) {
-            const uint64_t u = ubase + i;
-            uint4 v;
-            if (u < whole) {
-                v = in16[u];
-                v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
-            } else {
-                v.x = dec_load_word(p.in, p.in_bytes, u * 4 + 0);
-                v.y = dec_load_word(p.in, p.in_bytes, u * 4 + 1);
-                v.z = dec_load_word(p.in, p.in_bytes, u * 4 + 2);
-                v.w = dec_load_word(p.in, p.in_bytes, u * 4 + 3);
-            }
-            reinterpret_cast<uint4 *>(img)[i] = v;
-        }
-    }
-    DEC_TRACE(2);
-    __syncthreads();
-    DEC_TRACE(3);
-
-    const uint64_t sym0 = c * 64u;
-    const uint32_t cnt = valid ? (uint32_t)min((uint64_t)64u, p.n_out - sym0) : 0u;
-    const bool fast = use_lds && cnt == 64u;
-    bool bad = false;
-    const uint32_t row = off_rows + t * DECQ_ROW; // byte offset of this lane's row in LDS
-    if (fast) {
-        // LDS is addressed by plain 32-bit offsets here (the dynamic block starts at
-        // offset 0: the host checks that the kernel has no static LDS), so that the
-        // table index and the row position are the addresses themselves.
-        uint32_t pos = (off_img << 3) + s_lo + excl; // bit address of the lane's next code in LDS
-        uint32_t q = row;                            // byte address at which the next symbol goes
-        const uint32_t qend = row + 64u;
-        const uint32_t shift1 = 32u - p.w1;
-        while (q < qend) {
-            const uint32_t wa = (pos >> 3) & ~3u;
-            const uint32_t w0 = lds_load32(wa), w1 = lds_load32(wa + 4), w2 = lds_load32(wa + 8);
-            const uint32_t sh = 32u - (pos & 31u); // 1..32
-            const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
-            const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
-            uint64_t win = ((uint64_t)hi << 32) | lo;
-            uint32_t run = 0; // low byte: bits consumed in this group
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const uint32_t tix = ((uint32_t)(win >> 32) >> (32u - HF_QUAD_W - 3u)) & (((1u << HF_QUAD_W) - 1u) << 3);
-                u32x2 e = lds_load64(tix);
-                if (k == 0 && __builtin_expect(e.y < 0x100u, 0)) {
-                    // the first code does not end inside the index: one symbol
-                    // through the multi-level table (an undecodable window still
-                    // appends a byte, so the loop ends, and raises the flag)
-                    uint32_t e0 = s_lut[(uint32_t)(win >> 32) >> shift1];
-                    if (e0 & HF_LUT_ESC)
-                        e0 = dec_escape_window(win, e0, s_lut, p, bad);
-                    e.x = HF_LUT_SYM(e0) << 24;
-                    e.y = HF_LUT_LEN(e0) | 0x100u;
-                    if (HF_LUT_LEN(e0) > 64u - 4u * HF_QUAD_W) {
-                        // what is left of the window does not cover four more
-                        // look-ups: this code is the lane's whole group
-                        lds_or32(q & ~3u, __builtin_amdgcn_alignbyte(0u, e.x, q));
-                        q += 1u;
-                        pos += HF_LUT_LEN(e0);
-                        break;
-                    }
-                }
-                win <<= (e.y & 63u);
-                run += e.y;
-                // A row word holds its four symbols first-in-top-byte, like the entry:
-                // the entry moved down by the bytes the current word already holds
-                // completes that word, and what falls off starts the next one (a byte
-                // funnel shift takes its amount from the low two bits of q as they are).
-                const uint32_t wa2 = q & ~3u;
-                lds_or32(wa2, __builtin_amdgcn_alignbyte(0u, e.x, q));
-                lds_or32(wa2 + 4u, __builtin_amdgcn_alignbyte(e.x, 0u, q));
-                q = min(q + ((e.y >> 8) & 0xffu), qend);
-            }
-            pos += run & 0xffu; // (nothing yet when the group ended at its first code)
-        }
-        if (p.out_aligned16) {
-            *reinterpret_cast<uint32_t *>(smem + row + DECQ_ROW_FLAG) = 1u;
-        } else {
-            // (buffers at odd addresses: the lane stores its own bytes)
-            for (uint32_t i = 0; i < 64u; ++i)
-                p.out[sym0 + i] = smem[row + (i ^ 3u)];
-        }
-    } else if (cnt) {
-        // ragged chunk or oversized segment: bytes go straight to global memory
-        GlobalWords src{p.in, p.in_bytes, ubase * 4};
-        BitReader<GlobalWords> br(src, s_lo + excl);
-        const uint32_t shift = 32 - p.w1;
-        for (uint32_t i = 0; i < cnt; ++i) {
-            br.refill();
-            p.out[sym0 + i] = (uint8_t)dec_symbol<GlobalWords, true>(br, s_lut, shift, p, bad);
-        }
-    }
-    DEC_TRACE(4);
-    if (bad)
-        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
-    __syncthreads();
-    DEC_TRACE(5);
-    // rows that hold a whole chunk leave as 16-byte units, 64 contiguous bytes per chunk
-    if (seg_valid) {
-        uint8_t *obase = p.out + seg * (uint64_t)(HF_SEG_CHUNKS * 64u);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t u = t + k * HF_SEG_CHUNKS; // unit of the segment
-            const uint32_t r = off_rows + (u >> 2) * DECQ_ROW;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(smem + r + (u & 3u) * 16u);
-            const uint32_t flag = *reinterpret_cast<const uint32_t *>(smem + r + DECQ_ROW_FLAG);
-            const uint4 v = make_uint4(bswap32(src[0]), bswap32(src[1]), bswap32(src[2]), bswap32(src[3]));
-            if (flag)
-                *reinterpret_cast<uint4 *>(obase + u * 16u) = v;
-        }
-    }
-    DEC_TRACE(7);
 }
 
 // Gap-free decode: one lane walks the whole stream with predecessor search.

@@ -245,6 +245,8 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_sync_kernel(GapParams g)
     uint32_t *img = reinterpret_cast<uint32_t *>(smem + lut_bytes);
     uint32_t *s_exit = img + GAP_IMG_SLOTS;
 
+    if (W == 5 && !ESC)
+        HF_TOUCH_VGPR("v24"); // (24 registers otherwise, a shift amount in the last one)
     const uint64_t wg = blockIdx.x;
     const uint32_t st_in = g.first ? 0u : g.wg_in[wg];
     if (!g.first && st_in == g.wg_used[wg])

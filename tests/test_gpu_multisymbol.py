@@ -1,6 +1,8 @@
-"""GPU parity tests of the decoder that takes several symbols per table look-up
-(dec_kernel_quad; the reference's slice decoder is src/huffman/decode/mod.rs:167-231).
-Everything goes through the C ABI and is compared bit for bit with the CPU oracle."""
+"""GPU parity tests of the chunk-parallel decoder on steep codes, where short
+codes dominate and the long ones leave through the sub-tables and the key search
+(the reference's slice decoder is src/huffman/decode/mod.rs:167-231), and of the
+decode of the same streams without gap array.  Everything goes through the C ABI
+and is compared bit for bit with the CPU oracle."""
 import numpy as np
 import pytest
 
@@ -24,27 +26,12 @@ def to_gpu(a: np.ndarray):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-class forced_table:
-    """Models created inside get the several-symbols table whatever its yield."""
-
-    def __init__(self, dev):
-        self.ctx = dev.Context.get(torch.device("cuda", torch.cuda.current_device()))
-
-    def __enter__(self):
-        self.ctx.set_option("debug", 2048)
-        return self.ctx
-
-    def __exit__(self, *exc):
-        self.ctx.set_option("debug", 0)
-
-
-def roundtrip(dev, orc, data, codes, lens, *, oracle_decode=True, expect_kernel=True):
+def roundtrip(dev, orc, data, codes, lens, *, oracle_decode=True):
     model = dev.DeviceModel(codes, lens)
     enc = dev.encode(to_gpu(data), model)
     out = dev.decode(enc, model).cpu().numpy()
-    if expect_kernel:  # (a single symbol is no complete prefix code)
-        assert model.ctx.decode_kernel() == "dec_kernel_quad"
     assert np.array_equal(out, data)
+    assert np.array_equal(dev.decode_bare(enc.data, enc.nbytes, model, data.size).cpu().numpy(), data)
     if oracle_decode:
         stream = enc.stream().cpu().numpy()
         assert np.array_equal(out, orc.decode_read(stream, codes, lens, data.size))
@@ -53,21 +40,18 @@ def roundtrip(dev, orc, data, codes, lens, *, oracle_decode=True, expect_kernel=
 
 @pytest.mark.parametrize("kind", ["geometric", "testfile"])
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 16383, 16384, 16385, 32769, 300007, (1 << 20) + 77])
-def test_steep_streams_take_the_kernel_and_match_the_oracle(dev, orc, kind, n):
+def test_steep_streams_match_the_oracle(dev, orc, kind, n):
     data = synth.generate_host(kind, n, seed=41 + n)
     codes, lens = orc.generate_extended_codewords(orc.histogram(data))
-    roundtrip(dev, orc, data, codes, lens, expect_kernel=len(np.unique(data)) >= 2)
+    roundtrip(dev, orc, data, codes, lens)
 
 
 @pytest.mark.parametrize("kind", ["zipf", "uniform", "testfile", "geometric"])
-def test_any_complete_prefix_code_through_the_table(dev, orc, kind):
-    # one symbol per look-up (uniform), one to two (Zipf): the table is not worth
-    # having there, but it must decode them all the same
+def test_all_stream_kinds_with_and_without_gap_array(dev, orc, kind):
     n = 777777
     data = synth.generate_host(kind, n, seed=5)
     codes, lens = orc.generate_extended_codewords(orc.histogram(data))
-    with forced_table(dev):
-        roundtrip(dev, orc, data, codes, lens)
+    roundtrip(dev, orc, data, codes, lens)
 
 
 @pytest.mark.parametrize("nsym,growth", [(34, 2.0), (20, 2.3), (48, 1.7), (57, 1.62), (12, 3.0)])
@@ -85,13 +69,11 @@ def test_long_codes_leave_through_the_multi_level_table(dev, orc, nsym, growth):
     w = np.full(nsym, 1.0)
     w[: nsym // 2] = 4.0
     data = (100 + rng.choice(nsym, size=n, p=w / w.sum())).astype(np.uint8)
-    with forced_table(dev):
-        roundtrip(dev, orc, data, codes, lens)
+    roundtrip(dev, orc, data, codes, lens)
     # and with data that follows the model (short codes dominate)
     p = hist[100: 100 + nsym].astype(np.float64)
     data = (100 + rng.choice(nsym, size=n, p=p / p.sum())).astype(np.uint8)
-    with forced_table(dev):
-        roundtrip(dev, orc, data, codes, lens)
+    roundtrip(dev, orc, data, codes, lens)
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -108,8 +90,7 @@ def test_random_models_and_sizes(dev, orc, seed):
     n = int(rng.integers(1, 400000))
     p = hist[syms].astype(np.float64) ** float(rng.uniform(0.3, 1.0))
     data = syms[rng.choice(nsym, size=n, p=p / p.sum())].astype(np.uint8)
-    with forced_table(dev):
-        roundtrip(dev, orc, data, codes, lens)
+    roundtrip(dev, orc, data, codes, lens)
 
 
 @pytest.mark.parametrize("in_off,out_off", [(0, 1), (4, 0), (12, 7), (0, 16)])
@@ -128,7 +109,6 @@ def test_buffers_at_odd_addresses(dev, orc, in_off, out_off):
     dev.decode_async(moved[in_off:], enc.nbytes, model, n, 64, enc.chunk_bits, enc.seg_off, out[out_off:], res)
     torch.cuda.synchronize()
     assert int(res[1]) == 0
-    assert model.ctx.decode_kernel() == "dec_kernel_quad"
     assert np.array_equal(out[out_off: out_off + n].cpu().numpy(), data)
     assert int(out[out_off + n:].max()) == 0 and int(out[:out_off].sum()) == 0
 
@@ -143,7 +123,6 @@ def test_many_segments_per_cu_and_an_odd_segment_count(dev, orc):
     model = dev.DeviceModel(codes, lens)
     enc = dev.encode(t, model)
     out = dev.decode(enc, model)
-    assert model.ctx.decode_kernel() == "dec_kernel_quad"
     assert torch.equal(out, t)
     # the head and the tail bit for bit against the oracle's decoder
     head = 1 << 20

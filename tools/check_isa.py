@@ -3,20 +3,24 @@ the hardware mishandles:
 
     v_lshlrev_b64 v[a:b], vN, v[c:d]      with N = the wave's last allocated VGPR
 
-(likewise v_lshrrev_b64 / v_ashrrev_i64 and the other 64-bit results with 32-bit
-VGPR sources).  The 32-bit shift amount is fetched as a register pair; when its
-second half lies outside the wave's allocation (VGPRs are allocated in blocks of
+(likewise v_lshrrev_b64 and v_ashrrev_i64).  VGPRs are allocated in blocks of
 eight, so this needs a kernel whose register count is a multiple of eight and a
-register allocation that puts the amount into the very last one) the shift
-reads a wrong amount in waves that share their SIMD with earlier ones.  Seen with
-dec_kernel_reg<128, 6, false, false, false> at exactly 64 VGPRs and
-`v_lshlrev_b64 v[16:17], v63, v[14:15]`: every work-group that was not the
-first on its CU decoded wrong symbols from that shift on; the same instruction
-in a build that allocates one register more (65 -> 72) is right, and so is the
-kernel when only one work-group fits a CU.  The compiler does not avoid the
-pattern, so every build is checked (tests/test_isa_hazard.py).  If it trips:
-change the schedule or the register count of that kernel (a scheduling fence,
-an `asm volatile("" ::: "vN")` clobber one past the count) and build again.
+register allocation that puts the amount into the very last one; the shift
+then uses a wrong amount in every wave that is not the first on its SIMD.
+tools/ubench/shift_hazard.hip shows it with nothing but that instruction in
+the kernel (profiles/r03_ubench_shift_hazard.txt): the three 64-bit shifts all
+fail with the amount in v63 of 64 or v71 of 72 allocated registers, in every
+work-group after the first 256 (one per CU); the same instruction with the
+amount in v62, or in v63 with 72 registers allocated, is right, and so are
+v_mad_u64_u32, v_lshl_add_u64, v_cvt_f64_u32 and the 32-bit shifts with their
+32-bit source in the last register (the first two are scanned for all the
+same).  It was first met in dec_kernel_reg<128, 6, false, false, false> at
+exactly 64 VGPRs.  The compiler does not avoid the pattern, so the build
+(huffman_amd/build.py) scans the assembly it has just produced and refuses a
+library that contains it; tests/test_isa_hazard.py runs the same scan.  If it
+trips: HF_TOUCH_VGPR("v<count>") in that kernel (huffman_amd/csrc/dev_common.hpp)
+makes the count 8k + 1, so that the last register of the allocation is one no
+instruction names, whatever the schedule.
 
 usage: python tools/check_isa.py [file.s]   (without a file: compiles hfgpu.hip to assembly)
 Exit status 1 and one line per hit when the pattern occurs."""
