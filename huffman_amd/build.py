@@ -31,6 +31,11 @@ PROGRAMS = [
 ]
 
 
+# device micro-tests that a GPU test runs: (source, executable)
+UBENCH = [(os.path.join(ROOT, "tools", "ubench", "shift_hazard.hip"),
+           os.path.join(ROOT, "tools", "ubench", "shift_hazard"))]
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
@@ -73,7 +78,18 @@ def build_programs(force: bool = False, verbose: bool = False) -> list[str]:
     return out
 
 
+def build_ubench(force: bool = False, verbose: bool = False) -> None:
+    for src, exe in UBENCH:
+        if not force and os.path.exists(exe) and os.path.getmtime(src) <= os.path.getmtime(exe):
+            continue
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-w", "-o", exe, src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    build_ubench(force, verbose)
     if not force and not stale():
         build_programs(False, verbose)
         return LIB
