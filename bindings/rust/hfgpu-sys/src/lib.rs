@@ -41,6 +41,8 @@ pub const HF_NOALLOC_MAX_SYMBOLS: u64 = 1 << 32;
 pub const HF_TIMED_HISTOGRAM: c_int = 0;
 pub const HF_TIMED_ENCODE: c_int = 1;
 pub const HF_TIMED_DECODE: c_int = 2;
+pub const HF_TIMED_GAP_SYNC: c_int = 3;
+pub const HF_TIMED_GAP_WALK: c_int = 4;
 
 extern "C" {
     // ---- context

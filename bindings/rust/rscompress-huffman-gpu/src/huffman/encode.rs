@@ -5,6 +5,15 @@
 //! reference's bytes; `readbytes`, `fillbits` and, after `flush`, `writeout`
 //! are its values; `write`'s return value follows its put/cleanup schedule
 //! through counters while `track_write_value` is set.
+//!
+//! Like the reference's, `flush` does not reset the encoder (encode.rs:118-136):
+//! the bytes that were still in the reference's 64-bit buffer are emitted by the
+//! flush and stay in the buffer, so a second `flush` emits them again and a
+//! `write` after a `flush` continues in front of them.  Which bytes those are is
+//! part of the schedule: once `track_write_value` was clear at a `write`, an
+//! encoder that has been flushed refuses further use.  The gap array describes
+//! the one continuous bit stream; it is dropped when symbols follow a flush that
+//! ended inside a segment.
 use crate::gpu::{io_check, with_ctx, DeviceModel};
 use crate::model::Model;
 use hfgpu_sys as sys;
@@ -38,6 +47,11 @@ pub struct Encoder<'a, W: Write, M: Model> {
     pending: Vec<u8>,
     total_bits: u64,
     carry: u8,
+    // whole bytes of the reference's buffer at the last flush: out again first
+    resend: Vec<u8>,
+    flushed: bool,
+    gap_kept: bool,
+    schedule_valid: bool, // every symbol so far went through advance_schedule
     // the reference's {buffer, remaining_bits} (encode.rs:43-47), counters only
     buffer: u64,
     remaining_bits: u64,
@@ -51,6 +65,7 @@ impl<'a, W: Write, M: Model> Encoder<'a, W, M> {
             track_write_value: true,
             gap: GapArray { chunk_syms: 64, ..Default::default() },
             device: None, pending: Vec::new(), total_bits: 0, carry: 0,
+            resend: Vec::new(), flushed: false, gap_kept: true, schedule_valid: true,
             buffer: 0, remaining_bits: 64, schedule_writeout: 0,
         }
     }
@@ -98,65 +113,114 @@ impl<'a, W: Write, M: Model> Encoder<'a, W, M> {
         Ok(emitted + 8 - (self.buffer.trailing_zeros() / 8) as usize)
     }
 
+    fn refuse_after_untracked_flush(&self) -> std::io::Result<()> {
+        if self.flushed && !self.schedule_valid {
+            return Err(Error::new(ErrorKind::Other,
+                "Encoder used again after flush(): which bytes the reference emits again is only known with track_write_value set"));
+        }
+        Ok(())
+    }
+
     /// Encodes what is staged; whole bytes go to `inner`, a trailing partial
-    /// byte is carried into the next batch as lead bits unless this is the end.
+    /// byte is kept and merged into the next batch as lead bits -- after a
+    /// flush, which emits it, too.
     fn drain(&mut self, last: bool) -> std::io::Result<usize> {
         let seg_syms = sys::HF_SEG_CHUNKS as usize * self.gap.chunk_syms as usize;
         let n = if last { self.pending.len() } else { self.pending.len() / seg_syms * seg_syms };
         if n == 0 && !last {
             return Ok(0);
         }
+        let mut handed_on = 0usize;
+        if !self.resend.is_empty() {
+            let again = std::mem::take(&mut self.resend);
+            self.inner.write_all(&again)?;
+            handed_on += again.len();
+        }
+        if n > 0 && self.gap.symbols as usize % seg_syms != 0 {
+            self.gap = GapArray { chunk_syms: self.gap.chunk_syms, ..Default::default() };
+            self.gap_kept = false;
+        }
         let lead = (self.total_bits % 8) as u32;
         let handle = self.device()?.handle;
         let cap = unsafe { sys::hf_encode_bound(handle, n as u64, lead) } as usize + 8;
         let mut out: Vec<u8> = Vec::with_capacity(cap);
         let (mut nch, mut nsg) = (0u64, 0u64);
-        unsafe { sys::hf_gap_layout(n as u64, self.gap.chunk_syms, &mut nch, &mut nsg) };
+        if self.gap_kept {
+            unsafe { sys::hf_gap_layout(n as u64, self.gap.chunk_syms, &mut nch, &mut nsg) };
+        }
         let mut cb = vec![0u16; nch as usize];
         let mut so = vec![0u64; nsg as usize];
         let mut bits = 0u64;
-        with_ctx(|ctx| {
-            let rc = unsafe {
-                sys::hf_encode_host(ctx, handle, self.pending.as_ptr(), n as u64, lead,
-                                    out.as_mut_ptr(), cap as u64, self.gap.chunk_syms,
-                                    if n > 0 { cb.as_mut_ptr() } else { std::ptr::null_mut() },
-                                    if n > 0 { so.as_mut_ptr() } else { std::ptr::null_mut() },
-                                    &mut bits)
-            };
-            io_check(ctx, rc, "Encoder::flush")
-        })?;
+        if n > 0 {
+            let with_gap = self.gap_kept;
+            with_ctx(|ctx| {
+                let rc = unsafe {
+                    sys::hf_encode_host(ctx, handle, self.pending.as_ptr(), n as u64, lead,
+                                        out.as_mut_ptr(), cap as u64, self.gap.chunk_syms,
+                                        if with_gap { cb.as_mut_ptr() } else { std::ptr::null_mut() },
+                                        if with_gap { so.as_mut_ptr() } else { std::ptr::null_mut() },
+                                        &mut bits)
+                };
+                io_check(ctx, rc, "Encoder::flush")
+            })?;
+        } else {
+            // a flush with nothing staged: only the partial byte, if there is one
+            unsafe { *out.as_mut_ptr() = 0 };
+        }
         let mut nbytes = ((lead as u64 + bits + 7) / 8) as usize;
         unsafe { out.set_len(nbytes) };
-        let base_bit = self.total_bits - lead as u64;
-        self.gap.chunk_bits.extend_from_slice(&cb);
-        self.gap.seg_off.extend(so.iter().map(|v| v + base_bit));
-        self.gap.symbols += n as u64;
+        if self.gap_kept {
+            let base_bit = self.total_bits - lead as u64;
+            self.gap.chunk_bits.extend_from_slice(&cb);
+            self.gap.seg_off.extend(so.iter().map(|v| v + base_bit));
+            self.gap.symbols += n as u64;
+        }
         if lead != 0 && nbytes > 0 {
             out[0] |= self.carry;
         }
         self.total_bits += bits;
-        if !last && self.total_bits % 8 != 0 && nbytes > 0 {
+        let partial = self.total_bits % 8 != 0;
+        if partial && nbytes > 0 {
             self.carry = out[nbytes - 1];
+        }
+        if !last && partial && nbytes > 0 {
             nbytes -= 1;
-        } else if last {
-            self.fillbits = Some(((8 - self.total_bits % 8) % 8) as u8);
         }
         self.inner.write_all(&out[..nbytes])?;
-        if !self.track_write_value || last {
+        handed_on += nbytes;
+        if last {
+            self.fillbits = Some(((8 - self.total_bits % 8) % 8) as u8);
+            self.flushed = true;
+            if self.schedule_valid {
+                // encode.rs:119-133: what the flush has just emitted from the reference's
+                // buffer stays there; its whole bytes go out again before anything new
+                let held = self.buffer.to_be_bytes();
+                let length = 8 - (self.remaining_bits / 8) as usize;
+                self.resend = held[..length - partial as usize].to_vec();
+                self.schedule_writeout += length;
+                self.writeout = self.schedule_writeout;
+            } else {
+                self.writeout = ((self.total_bits + 7) / 8) as usize;
+            }
+        } else if !self.track_write_value || !self.schedule_valid {
             self.writeout = ((self.total_bits + 7) / 8) as usize;
         }
         self.pending.drain(..n);
-        Ok(nbytes)
+        Ok(handed_on)
     }
 }
 
 impl<'a, W: Write, M: Model> Write for Encoder<'a, W, M> {
     fn write(&mut self, buf: &[u8]) -> std::io::Result<usize> {
         self.device()?;
+        self.refuse_after_untracked_flush()?;
         let mut ret = 0usize;
-        if self.track_write_value {
+        let replay = self.track_write_value && self.schedule_valid;
+        if replay {
             ret = self.advance_schedule(buf)?;
             self.writeout = self.schedule_writeout;
+        } else if !buf.is_empty() {
+            self.schedule_valid = false;
         }
         self.readbytes += buf.len();
         if self.pending.len() + buf.len() > (1 << 20) && self.pending.capacity() < STAGE_LIMIT {
@@ -167,11 +231,11 @@ impl<'a, W: Write, M: Model> Write for Encoder<'a, W, M> {
         if self.pending.len() >= STAGE_LIMIT {
             emitted = self.drain(false)?;
         }
-        Ok(if self.track_write_value { ret } else { emitted })
+        Ok(if replay { ret } else { emitted })
     }
-    /// Like the reference's, a flush does not reset the encoder.
     fn flush(&mut self) -> std::io::Result<()> {
         self.device()?;
+        self.refuse_after_untracked_flush()?;
         self.drain(true)?;
         self.inner.flush()
     }

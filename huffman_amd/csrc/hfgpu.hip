@@ -91,7 +91,7 @@ struct hf_ctx {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ring;
         size_t pending = 0; // pairs recorded since the last collection
     };
-    Timed timed[3];
+    Timed timed[HF_TIMED_KINDS];
     bool kernel_timing = false;
     const char *encode_kernel = ""; // what the last encode launched over its complete batches
     const char *decode_kernel = ""; // what the last hf_decode[_async] launched
@@ -509,7 +509,7 @@ const char *hf_ctx_decode_kernel(const hf_ctx *ctx) { return ctx ? ctx->decode_k
 int hf_ctx_kernel_ms(hf_ctx *ctx, int kind, double *sum_ms, uint64_t *launches)
 {
     DeviceGuard on(ctx);
-    if (!ctx || kind < 0 || kind > 2 || !sum_ms || !launches)
+    if (!ctx || kind < 0 || kind >= HF_TIMED_KINDS || !sum_ms || !launches)
         return HF_ERR_BAD_ARG;
     HF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hf_ctx::Timed &t = ctx->timed[kind];
@@ -1395,13 +1395,14 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
     const dim3 wgs((uint32_t)g.n_wg), one_per_wg((uint32_t)((g.n_wg + GAP_THREADS - 1) / GAP_THREADS));
     auto last_walk = [&]() { // gap array and / or symbols from the final starts
         if (gaps) {
-            hipLaunchKernelGGL(kern.emit, wgs, dim3(GAP_THREADS), lds, ctx->stream, g);
+            HF_TIMED_LAUNCH(ctx, HF_TIMED_GAP_WALK,
+                            hipLaunchKernelGGL(kern.emit, wgs, dim3(GAP_THREADS), lds, ctx->stream, g));
             hipLaunchKernelGGL(gap_diff_kernel,
                                dim3((uint32_t)((g.n_chunks + GAP_THREADS - 1) / GAP_THREADS)),
                                dim3(GAP_THREADS), 0, ctx->stream, g);
         }
         if (d_out)
-            HF_TIMED_LAUNCH(ctx, HF_TIMED_DECODE,
+            HF_TIMED_LAUNCH(ctx, HF_TIMED_GAP_WALK,
                             hipLaunchKernelGGL(kern.decode, wgs, dim3(GAP_THREADS), lds, ctx->stream, g));
     };
     // The first launch lets every work-group assume its first start (from a walk
@@ -1417,7 +1418,8 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
     for (uint64_t round = 0;; ++round) {
         if (round > g.n_wg + 1)
             return fail(ctx, HF_ERR_INTERNAL, "hf_build_gap_array: no fixed point");
-        hipLaunchKernelGGL(kern.sync, wgs, dim3(GAP_THREADS), lds, ctx->stream, g);
+        HF_TIMED_LAUNCH(ctx, HF_TIMED_GAP_SYNC,
+                        hipLaunchKernelGGL(kern.sync, wgs, dim3(GAP_THREADS), lds, ctx->stream, g));
         HF_HIP(ctx, hipGetLastError());
         g.first = 0;
         HF_HIP(ctx, hipMemsetAsync(g.changed, 0, 4, ctx->stream));

@@ -95,8 +95,18 @@ HF_API int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value);
  * the decode kernel) with HIP events on the stream it is launched on.  This waits for the context's
  * stream, returns the summed duration and the number of launches since the
  * last collection (at most 4096 are kept) and starts over.  A measuring aid
- * without counterpart in the reference. */
-enum { HF_TIMED_HISTOGRAM = 0, HF_TIMED_ENCODE = 1, HF_TIMED_DECODE = 2 };
+ * without counterpart in the reference.
+ * The bare-stream calls (hf_build_gap_array, hf_decode_bare) bracket each launch of
+ * gap_sync_kernel (HF_TIMED_GAP_SYNC) and their last walk, gap_decode_kernel or
+ * gap_emit_kernel (HF_TIMED_GAP_WALK). */
+enum {
+    HF_TIMED_HISTOGRAM = 0,
+    HF_TIMED_ENCODE = 1,
+    HF_TIMED_DECODE = 2,
+    HF_TIMED_GAP_SYNC = 3,
+    HF_TIMED_GAP_WALK = 4,
+    HF_TIMED_KINDS = 5
+};
 HF_API int hf_ctx_kernel_ms(hf_ctx *ctx, int kind, double *sum_ms, uint64_t *launches);
 /* Name of the kernel the context's last encode call launched over its complete
  * batches ("enc_pack_stream_kernel", "enc_pack_kernel", "enc_bytes_kernel"; ""

@@ -354,41 +354,120 @@ namespace encode {
 // calculate_length (src/huffman/encode.rs:140-149)
 inline usize calculate_length(usize val) { return hf_calculate_length(val); }
 
-// The byte-emission bookkeeping of Encoder::write (src/huffman/encode.rs:57-116)
-// without the bytes: how many bytes `put` (:57-66) and `cleanup` (:67-83) hand
-// to the inner writer while the symbols of one call pass, and what the call
-// returns (:115).  Pure counter arithmetic on {buffer, remaining_bits,
-// writeout}; the stream itself is produced on the GPU.  hf_encoder_write_value
-// replays the same schedule on the device and is what the tests hold this
-// against.
+// The byte-emission bookkeeping of Encoder::write and ::flush
+// (src/huffman/encode.rs:57-136) without the inner writer: the reference's
+// {buffer, remaining_bits, writeout} (:43-47), how many bytes `put` (:57-66)
+// and `cleanup` (:67-83) hand on while the symbols of one call pass, what the
+// call returns (:115), and the bytes a flush emits (:118-136).  The stream
+// itself is produced on the GPU.  hf_encoder_write_value replays the same
+// schedule on the device and is what the tests hold this against.
+//
+// advance() does not run the reference's loop symbol by symbol.  While a code
+// still ends above bit 24 of the buffer neither `put` (the code fits) nor
+// `cleanup` (bits 16-23 stay clear) can happen, and the bits themselves are
+// not looked at until they are written out: such symbols only move
+// remaining_bits, two at a time where a pair fits.  The others take the
+// reference's step on a buffer whose low 24 bits are exact -- all that the
+// cleanup test reads.  The buffer is made exact again at the end of the call
+// by taking the symbols since the last cleanup once more, bits included.
 struct WriteSchedule {
     usize buffer = 0, remaining_bits = 64, writeout = 0; // encode.rs:43-47
+
+    void set_codes(const std::array<usize, 256> &codes, const std::array<usize, 256> &lens)
+    {
+        codes_ = &codes;
+        lens_ = &lens;
+        for (int a = 0; a < 256; ++a)
+            len8_[a] = (u8)std::min<usize>(lens[a], 255);
+        pair_.reset(new u8[65536]);
+        for (int a = 0; a < 256; ++a) // (index = the two bytes as they lie in memory, either byte order)
+            for (int b = 0; b < 256; ++b) {
+                const u8 two[2] = {(u8)a, (u8)b};
+                std::uint16_t at;
+                std::memcpy(&at, two, 2);
+                pair_[at] = (u8)std::min<usize>((usize)len8_[a] + len8_[b], 255);
+            }
+    }
+    // One symbol as the reference takes it (encode.rs:93-112); returns the bytes emitted.
+    usize step(u8 sym)
+    {
+        const usize code = (*codes_)[sym], len = (*lens_)[sym];
+        usize emitted = 0;
+        if (len > 64)
+            throw IoError(true, "Codelen > 64"); // encode.rs:102-104
+        while (len > remaining_bits) { // put: one byte out
+            emitted += 1;
+            buffer <<= 8;
+            remaining_bits += 8;
+        }
+        remaining_bits -= len;
+        buffer += code << (remaining_bits & 63);
+        if (buffer & 0x0000000000FF0000ull) { // cleanup: five bytes out
+            emitted += 5;
+            buffer <<= 40;
+            remaining_bits += 40;
+        }
+        return emitted;
+    }
     // Returns the value Encoder::write returns for these symbols.
-    usize advance(const u8 *buf, std::size_t n, const std::array<usize, 256> &codes,
-                  const std::array<usize, 256> &lens)
+    usize advance(const u8 *buf, std::size_t n)
     {
         usize emitted = 0;
-        for (std::size_t i = 0; i < n; ++i) {
-            const usize code = codes[buf[i]], len = lens[buf[i]];
-            if (len > 64)
-                throw IoError(true, "Codelen > 64"); // encode.rs:102-104
-            while (len > remaining_bits) { // put: one byte out
-                emitted += 1;
-                buffer <<= 8;
-                remaining_bits += 8;
+        std::size_t i = 0, exact_from = 0; // `buffer` lacks bits of the symbols [exact_from, i)
+        usize exact_buffer = buffer, exact_remaining = remaining_bits;
+        const u8 *len8 = len8_, *pair = pair_.get();
+        while (i < n) {
+            usize r = remaining_bits;
+            while (i + 2 <= n) {
+                std::uint16_t two;
+                std::memcpy(&two, buf + i, 2);
+                const usize l2 = pair[two];
+                if (r < l2 + 24)
+                    break;
+                r -= l2;
+                i += 2;
             }
-            remaining_bits -= len;
-            buffer += code << (remaining_bits & 63);
-            if (buffer & 0x0000000000FF0000ull) { // cleanup: five bytes out
-                emitted += 5;
-                buffer <<= 40;
-                remaining_bits += 40;
+            while (i < n && r >= (usize)len8[buf[i]] + 24) {
+                r -= len8[buf[i]];
+                ++i;
+            }
+            remaining_bits = r;
+            if (i == n)
+                break;
+            const usize e = step(buf[i++]);
+            emitted += e;
+            if (e >= 5) { // a cleanup: everything that is left lay in the exact low bits
+                exact_from = i;
+                exact_buffer = buffer;
+                exact_remaining = remaining_bits;
             }
         }
+        const usize end_remaining = remaining_bits;
+        buffer = exact_buffer;
+        remaining_bits = exact_remaining;
+        for (std::size_t k = exact_from; k < n; ++k)
+            step(buf[k]);
+        if (remaining_bits != end_remaining)
+            throw Panic(HF_ERR_INTERNAL, "WriteSchedule: the two passes disagree");
         writeout += emitted;
         const usize tz = buffer ? (usize)__builtin_ctzll(buffer) : 64;
         return emitted + 8 - tz / 8;
     }
+    // flush (encode.rs:118-136): the bytes of the buffer that hold bits; state unchanged
+    // but for `writeout`.  Returns their number; out[0 .. that) receives them.
+    usize flush(u8 out[8])
+    {
+        for (int k = 0; k < 8; ++k)
+            out[k] = (u8)(buffer >> (56 - 8 * k));
+        const usize length = 8 - remaining_bits / 8;
+        writeout += length;
+        return length;
+    }
+
+  private:
+    const std::array<usize, 256> *codes_ = nullptr, *lens_ = nullptr;
+    u8 len8_[256] = {};
+    std::unique_ptr<u8[]> pair_;
 };
 
 // struct Encoder<'a, W: Write, M: Model> (src/huffman/encode.rs:26-34).
@@ -396,12 +475,22 @@ struct WriteSchedule {
 // STAGE_LIMIT bytes are pending): the reference's progressive inner writes
 // are not observable in the final stream.  The return value of write() and
 // `writeout` between calls follow the reference's put/cleanup schedule
-// exactly while `track_write_value` is set (WriteSchedule: counters only, on
-// the host, no device round trip per call).  Otherwise write() returns the
-// bytes it really handed to `inner` during the call (0 while staging) and
-// `writeout` is exact again after flush().  Callers that ignore the return
-// value, like the file compressor below, clear the flag and save the pass
-// over the symbols.
+// exactly while `track_write_value` is set (WriteSchedule: on the host, no
+// device round trip per call).  Otherwise write() returns the bytes it really
+// handed to `inner` during the call (0 while staging) and `writeout` is exact
+// again after flush().  Callers that ignore the return value, like the file
+// compressor below, clear the flag and save the pass over the symbols.
+//
+// Like the reference's, flush() does not reset the encoder: the bytes that
+// were still in the reference's 64-bit buffer are emitted by the flush and
+// stay in the buffer, so a second flush() emits them again and a write()
+// after a flush() continues in front of them (encode.rs:118-136).  Which bytes
+// those are is part of the schedule: with `track_write_value` cleared at any
+// write() so far (setting it again later does not bring the schedule back), an
+// encoder that has been flushed refuses further use.
+// The gap array describes the one continuous bit stream, not the bytes that
+// were handed on twice; it is dropped when symbols follow a flush that ended
+// inside a segment.
 template <class W>
 class Encoder {
   public:
@@ -426,11 +515,14 @@ class Encoder {
     usize write(const u8 *buf, std::size_t n)
     {
         ensure_device_model();
+        refuse_after_untracked_flush();
         usize ret = 0;
-        const bool replay = track_write_value;
+        const bool replay = track_write_value && schedule_valid_;
         if (replay) {
-            ret = schedule_.advance(buf, n, dm_->codes(), dm_->lens());
+            ret = schedule_.advance(buf, n);
             writeout = schedule_.writeout;
+        } else if (n) {
+            schedule_valid_ = false;
         }
         readbytes += n;
         // (one reservation instead of doubling: a growing vector would hold two
@@ -445,11 +537,11 @@ class Encoder {
     }
     usize write(const std::vector<u8> &buf) { return write(buf.data(), buf.size()); }
 
-    // impl Write::flush (encode.rs:118-136); like the reference it does not
-    // reset the encoder.
+    // impl Write::flush (encode.rs:118-136)
     void flush()
     {
         ensure_device_model();
+        refuse_after_untracked_flush();
         drain(true);
         inner.flush();
     }
@@ -464,8 +556,16 @@ class Encoder {
   private:
     void ensure_device_model()
     {
-        if (!dm_)
+        if (!dm_) {
             dm_ = std::make_unique<DeviceModel>(*model);
+            schedule_.set_codes(dm_->codes(), dm_->lens());
+        }
+    }
+    void refuse_after_untracked_flush() const
+    {
+        if (flushed_ && !schedule_valid_)
+            throw IoError(false, "Encoder used again after flush(): which bytes the reference "
+                                 "emits again is only known with track_write_value set");
     }
     void write_all(const u8 *b, std::size_t n)
     {
@@ -477,8 +577,8 @@ class Encoder {
             off += k;
         }
     }
-    // Encodes what is staged.  Whole bytes go to `inner`; when !final the last
-    // partial byte is kept and merged into the next batch (lead bits).
+    // Encodes what is staged.  Whole bytes go to `inner`; the last partial byte is kept
+    // and merged into the next batch (lead bits) -- after a flush, which emits it, too.
     void drain(bool final)
     {
         const std::uint32_t lead = (std::uint32_t)(total_bits_ % 8);
@@ -486,49 +586,84 @@ class Encoder {
         const usize n = final ? pending_.size() : pending_.size() - pending_.size() % seg_syms;
         if (n == 0 && !final)
             return;
+        // whole bytes the reference still had in its buffer at the last flush: out again
+        if (!resend_.empty()) {
+            write_all(resend_.data(), resend_.size());
+            emitted_ += resend_.size();
+            resend_.clear();
+        }
         // (not value-initialised: only the bytes the stream really has are touched)
         const std::size_t out_cap = hf_encode_bound(dm_->handle(), n, lead) + 8;
         std::unique_ptr<u8[]> out(new u8[out_cap]);
+        // symbols that follow a flush in the middle of a segment: the chunks would no
+        // longer be of one size, so no gap array from here on (decoders then find the
+        // code boundaries themselves)
+        if (n && gap_.symbols % seg_syms != 0) {
+            gap_ = GapArray{};
+            gap_kept_ = false;
+        }
         usize nch = 0, nsg = 0;
-        hf_gap_layout(n, gap_.chunk_syms, &nch, &nsg);
+        if (gap_kept_)
+            hf_gap_layout(n, gap_.chunk_syms, &nch, &nsg);
         std::vector<std::uint16_t> cb(nch);
         std::vector<usize> so(nsg);
         usize bits = 0;
-        Runtime::check(hf_encode_host(Runtime::ctx(), dm_->handle(), pending_.data(), n, lead,
-                                      out.get(), out_cap, gap_.chunk_syms,
-                                      n ? cb.data() : nullptr, n ? so.data() : nullptr, &bits),
-                       "Encoder::flush");
+        if (n)
+            Runtime::check(hf_encode_host(Runtime::ctx(), dm_->handle(), pending_.data(), n, lead,
+                                          out.get(), out_cap, gap_.chunk_syms,
+                                          gap_kept_ ? cb.data() : nullptr,
+                                          gap_kept_ ? so.data() : nullptr, &bits),
+                           "Encoder::flush");
+        else
+            out[0] = 0; // a flush with nothing staged: only the partial byte, if there is one
         // gap array: segment offsets become absolute; batches are only cut at
         // multiples of a segment, so the arrays simply concatenate
-        const usize base_bit = total_bits_ - lead;
-        for (auto &v : so)
-            v += base_bit;
-        gap_.chunk_bits.insert(gap_.chunk_bits.end(), cb.begin(), cb.end());
-        gap_.seg_off.insert(gap_.seg_off.end(), so.begin(), so.end());
-        gap_.symbols += n;
+        if (gap_kept_) {
+            const usize base_bit = total_bits_ - lead;
+            for (auto &v : so)
+                v += base_bit;
+            gap_.chunk_bits.insert(gap_.chunk_bits.end(), cb.begin(), cb.end());
+            gap_.seg_off.insert(gap_.seg_off.end(), so.begin(), so.end());
+            gap_.symbols += n;
+        }
         usize nbytes = (lead + bits + 7) / 8;
         if (lead && nbytes)
             out[0] |= carry_;
         total_bits_ += bits;
         const bool partial = (total_bits_ % 8) != 0;
-        if (!final && partial && nbytes) {
+        if (partial && nbytes)
             carry_ = out[nbytes - 1];
+        if (!final && partial && nbytes)
             --nbytes;
-        } else if (final) {
-            fillbits = (u8)((8 - total_bits_ % 8) % 8);
-        }
         write_all(out.get(), nbytes);
         emitted_ += nbytes;
-        if (!track_write_value || final)
+        if (final) {
+            fillbits = (u8)((8 - total_bits_ % 8) % 8);
+            flushed_ = true;
+            if (schedule_valid_) {
+                // encode.rs:119-133: what the flush has just emitted from the reference's
+                // buffer stays there; its whole bytes go out again before anything new
+                u8 held[8];
+                const usize length = schedule_.flush(held);
+                resend_.assign(held, held + (length - (partial ? 1 : 0)));
+                writeout = schedule_.writeout;
+            } else {
+                writeout = (total_bits_ + 7) / 8;
+            }
+        } else if (!track_write_value || !schedule_valid_) {
             writeout = (total_bits_ + 7) / 8;
+        }
         pending_.erase(pending_.begin(), pending_.begin() + (std::ptrdiff_t)n);
     }
 
     std::unique_ptr<DeviceModel> dm_;
-    std::vector<u8> pending_;
+    std::vector<u8> pending_, resend_;
     GapArray gap_;
     usize total_bits_ = 0, emitted_ = 0;
     u8 carry_ = 0;
+    bool flushed_ = false;
+    bool gap_kept_ = true;
+    bool schedule_valid_ = true; // every symbol so far went through schedule_
     WriteSchedule schedule_;
 };
 

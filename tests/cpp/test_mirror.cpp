@@ -115,6 +115,61 @@ int main()
         CHECK(output_bytes == 9);
         CHECK(enc.readbytes == 10 && enc.writeout == 9);
     });
+    // src/huffman/encode.rs:118-136: flush does not reset.  A second flush emits the
+    // bytes of the 64-bit buffer again, a write after a flush continues in front of
+    // them.  Expected bytes and counters: the reference's algorithm (its CPU
+    // restatement) run on these very calls.
+    run("flush_twice_and_write_after_flush", [] {
+        Huffman h = numbers_model();
+        {
+            Encoder<VecWriter> enc(VecWriter{}, h);
+            CHECK(enc.write(WORDS) == 9 && enc.writeout == 5);
+            enc.flush();
+            CHECK((enc.inner.get_ref() == std::vector<u8>{177, 225, 82, 62, 83, 14, 151, 58, 42}));
+            CHECK(enc.writeout == 9 && *enc.fillbits == 0);
+            enc.flush();
+            CHECK((enc.inner.get_ref() ==
+                   std::vector<u8>{177, 225, 82, 62, 83, 14, 151, 58, 42, 14, 151, 58, 42}));
+            CHECK(enc.writeout == 13 && *enc.fillbits == 0);
+            CHECK(enc.write(WORDS.data(), 4) == 8 && enc.writeout == 18 && enc.readbytes == 14);
+            enc.flush();
+            CHECK((enc.inner.get_ref() == std::vector<u8>{177, 225, 82, 62, 83, 14,  151, 58, 42, 14, 151,
+                                                         58,  42,  14, 151, 58, 42, 177, 225, 82, 60}));
+            CHECK(enc.writeout == 21 && *enc.fillbits == 2);
+        }
+        {
+            // the stream ends inside a byte at the first flush
+            Encoder<VecWriter> enc(VecWriter{}, h);
+            CHECK(enc.write(WORDS.data(), 3) == 3 && enc.writeout == 0);
+            enc.flush();
+            CHECK((enc.inner.get_ref() == std::vector<u8>{177, 225, 80}) && enc.writeout == 3);
+            CHECK(*enc.fillbits == 2);
+            enc.flush();
+            CHECK((enc.inner.get_ref() == std::vector<u8>{177, 225, 80, 177, 225, 80}) && enc.writeout == 6);
+            CHECK(enc.write(WORDS.data() + 3, 7) == 9 && enc.writeout == 11);
+            enc.flush();
+            CHECK((enc.inner.get_ref() == std::vector<u8>{177, 225, 80, 177, 225, 80, 177, 225, 82, 62, 83, 14,
+                                                         151, 58, 42}));
+            CHECK(enc.writeout == 15 && *enc.fillbits == 0);
+            // chunks of one size no longer describe this stream: the gap array is dropped
+            CHECK(!enc.gap().fits(10, 9));
+        }
+        {
+            // without the schedule the bytes to repeat are not known: refused, not guessed
+            Encoder<VecWriter> enc(VecWriter{}, h);
+            enc.track_write_value = false;
+            enc.write(WORDS);
+            enc.flush();
+            CHECK((enc.inner.get_ref() == std::vector<u8>{177, 225, 82, 62, 83, 14, 151, 58, 42}));
+            bool refused = false;
+            try {
+                enc.flush();
+            } catch (const IoError &) {
+                refused = true;
+            }
+            CHECK(refused);
+        }
+    });
     // src/huffman/encode.rs:188-205 encode_stream
     run("encode_stream", [] {
         std::array<usize, 256> codewords{}, length{};

@@ -170,6 +170,43 @@ static void run_case(uint64_t seed, const std::string &dir)
     CHECK(enc.gap().fits(n, stream.size()), "gap array of the encoder fits its stream");
     orc_encoder_free(oe);
 
+    // flush() in the middle, twice in a row, and write() after it: the reference does not
+    // reset, its buffer's bytes go out again (src/huffman/encode.rs:118-136)
+    if (n <= (1u << 20) || r() % 4 == 0) {
+        orc_encoder *of = orc_encoder_new(ocodes, olens);
+        huffman::encode::Encoder<VecWriter> ef(VecWriter{}, h);
+        const std::size_t max_piece = 1 + log_uniform(r, 200000);
+        std::size_t at = 0;
+        int flushes = 0;
+        while (at < n || flushes < 2) {
+            if (at < n && r() % 3) {
+                const std::size_t k = std::min<std::size_t>(n - at, 1 + r() % max_piece);
+                const usize ret = ef.write(data.data() + at, k);
+                CHECK((int64_t)ret == orc_encoder_write(of, data.data() + at, k), "write() value around flushes");
+                at += k;
+            } else {
+                ef.flush();
+                orc_encoder_flush(of);
+                ++flushes;
+                CHECK(ef.fillbits && (int32_t)*ef.fillbits == orc_encoder_fillbits(of), "fillbits of a repeated flush");
+            }
+            CHECK(ef.writeout == orc_encoder_writeout(of), "writeout around flushes");
+            const auto &got = ef.inner.get_ref();
+            if (flushes && (at == n || r() % 4 == 0)) // (what is still staged is not out yet)
+                if (at == n || got.size() == orc_encoder_len(of))
+                    CHECK(got.size() <= orc_encoder_len(of) &&
+                              std::memcmp(got.data(), orc_encoder_data(of), got.size()) == 0,
+                          "bytes around flushes");
+        }
+        ef.flush();
+        orc_encoder_flush(of);
+        const auto &got = ef.inner.get_ref();
+        CHECK(got.size() == orc_encoder_len(of) && std::memcmp(got.data(), orc_encoder_data(of), got.size()) == 0,
+              "bytes after repeated flushes");
+        CHECK(ef.writeout == orc_encoder_writeout(of), "writeout after repeated flushes");
+        orc_encoder_free(of);
+    }
+
     // Decoder::new: with the encoder's gap array, short reads from the inner reader
     {
         huffman::decode::Decoder<ShortReader> dec(ShortReader(stream, seed * 5 + 2, 1 + log_uniform(r, 200000)), enc);
