@@ -10,14 +10,19 @@ on the launch stream, inside the timed region) are reported alongside.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N = 1: the headline workload is the 1 GiB Zipf(s=1.1) stream.  Unless a single
-workload is asked for with --kind / --gib, the same process then measures the
-other single-GPU configurations -- 1 GiB uniform, 4 GiB geometric(p=0.5) and
-the 16 GiB Zipf stream that the multi-GPU runs split -- and reports them in
-the "configs" array of the same JSON line.
+Every N measures the same workload: ONE logical 16 GiB Zipf(s=1.1) stream
+(--total-gib) cut into N contiguous shards of 16/N GiB, one rank per GPU
+(strong scaling; at N = 1 the single shard is the whole stream).  Unless a
+single workload is asked for with --kind / --gib, the N = 1 run then measures
+the other single-GPU configurations -- 1 GiB Zipf, 1 GiB uniform, 4 GiB
+geometric(p=0.5) -- and reports them in the "configs" array of the same JSON
+line.  Every record also carries "decode_nogap": the decode of the bare stream
+without its gap array (hf_decode_bare, what a file written by the reference
+itself needs), timed outside the round trip.  "adaptors" holds the rates of the
+streaming Encoder::write / Decoder::read adaptors driven the way the
+reference's callers drive them (tools/src/adaptor_rate.cpp, host buffers).
 
-N > 1: ONE logical 16 GiB Zipf stream (--total-gib) is cut into N contiguous
-shards of 16/N GiB, one rank per GPU (strong scaling).  The 256-bin histograms
+N > 1: the 256-bin histograms
 are all-gathered over RCCL, every rank sums them and builds the same codebook,
 and the exclusive scan of the shards' bit lengths (histogram row x code
 lengths) places each shard at its own bit phase of the global stream.  The
@@ -48,7 +53,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps (default 100 at N=1, 20 for the 16 GiB stream at N>1)")
+                    help="timed steps of the headline workload (default 20)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--kind", default=None, choices=["zipf", "uniform", "geometric", "testfile"])
     ap.add_argument("--gib", type=float, default=None,
@@ -65,7 +70,8 @@ def parse():
                     help="workgroups of the counting pass (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
-                    help="N=1: skip the uniform / geometric / 16 GiB sub-records")
+                    help="N=1: skip the 1 GiB Zipf / uniform / 4 GiB geometric sub-records")
+    ap.add_argument("--no-adaptors", action="store_true", help="skip the adaptor rates")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--lib-debug", type=int, default=0,
                     help="the library's \"debug\" option (timing experiments: 64 = the other "
@@ -229,6 +235,10 @@ def run_workload(args, env, kind: str, n: int, steps: int, warmup: int) -> dict:
 
     ms_step = elapsed / steps * 1e3
     C = state["nbytes"]
+    nogap = None
+    if not use_dist and ok:
+        nogap = bare_decode(ctx, hd, torch, bufs, state["model"], C, n, out, data, kind, cs)
+        ok = ok and nogap["ok"]
     # per stage: HIP events around the whole call (helper kernels and launch gaps
     # included); per kernel: the library's events around the dominant kernel alone,
     # which is what a rocprofv3 kernel trace of this command reports as well
@@ -283,11 +293,94 @@ def run_workload(args, env, kind: str, n: int, steps: int, warmup: int) -> dict:
         "hbm_frac": {k: round(v["GBps"] / HBM_PEAK_GBPS, 4) for k, v in kernels.items()},
         "roofline": roofline,
     }
+    if nogap is not None:
+        rec["decode_nogap"] = nogap
+        rec["roundtrip_ok"] = ok
     if use_dist and state["plan"] is not None:
         rec["stream_total_bytes"] = state["plan"].total_bytes
     env["last_data"] = data if not use_dist else None
     del out, bufs, batch_hist
     return rec
+
+
+def bare_decode(ctx, hd, torch, bufs, model, C: int, n: int, out, data, kind: str, cs: int) -> dict:
+    """hf_decode_bare on the stream the last step left in `bufs`: the decode of a
+    stream that comes without a gap array (the reference's own files,
+    src/lib.rs:31-80).  Host clock around the synchronous call, HIP events around
+    its two heavy kernels: gap_sync_kernel finds the code boundaries (every lane
+    walks its 512 bits of the stream until it meets its neighbour's walk), then
+    gap_decode_kernel walks once more and writes the symbols."""
+    calls = 5 if n <= (4 << 30) else 3
+    out.zero_()
+    hd.decode_bare(bufs.data, C, model, n, out)  # warm-up (scratch allocation)
+    good = bool(torch.equal(out, data))
+    torch.cuda.synchronize()
+    for kind_id in (3, 4):
+        ctx.kernel_ms(kind_id)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        hd.decode_bare(bufs.data, C, model, n, out)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / calls * 1e3
+    sync_ms, sync_launches = ctx.kernel_ms(3)
+    walk_ms, walk_launches = ctx.kernel_ms(4)
+    good = good and bool(torch.equal(out, data))
+    alg = C + n
+    rec = {
+        "entry": "hf_decode_bare",
+        "ok": good,
+        "calls": calls,
+        "ms": round(ms, 4),
+        "alg_bytes": alg,
+        "GBps": round(alg / (ms * 1e-3) / 1e9, 1),
+        "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "decode_GBps_uncompressed": round(n / (ms * 1e-3) / 1e9, 1),
+        "kernel_ms": {"gap_sync_kernel": round(sync_ms / calls, 4),
+                      "gap_decode_kernel": round(walk_ms / calls, 4)},
+        "launches_per_call": {"gap_sync_kernel": sync_launches / calls,
+                              "gap_decode_kernel": walk_launches / calls},
+    }
+    for name, key in (("gap_sync_kernel", "gap_sync"), ("gap_decode_kernel", "gap_decode")):
+        traffic, source = pmc_traffic(kind, n, cs, key)
+        if traffic is not None:
+            rec.setdefault("traffic", {})[name] = traffic
+            rec["traffic_source"] = source
+    return rec
+
+
+def adaptor_rates() -> dict | None:
+    """Encoder::write in 4096-byte calls (src/lib.rs:68-77) with and without the
+    write() value tracked, Decoder::read in 15-byte calls (examples/decode.rs:55-73)
+    with and without the gap array: the C++ mirror of the reference's adaptors over
+    host buffers, run as a child process (tools/bin/adaptor_rate --json)."""
+    exe = os.path.join(ROOT, "tools", "bin", "adaptor_rate")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "256", "--json"], capture_output=True, text=True, timeout=300)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return {"error": str(e)}
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": (r.stdout + r.stderr)[-300:]}
+
+
+def cpu_identity() -> dict:
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 0
+    return {"cpu_model": model, "host_cpus": os.cpu_count() or 0, "usable_cpus": usable}
 
 
 def pmc_traffic(kind: str, n: int, cs: int, kernel: str):
@@ -330,6 +423,7 @@ def cpu_baseline(data, sample_mib: int) -> dict:
         "value": round(m / (t3 - t0) / 1e9, 4),
         "unit": "GB/s",
         "cores": 1,
+        **cpu_identity(),
         "kind": "port",
         "sample": f"first {m >> 20} MiB of the same stream; histogram+codebook {t1 - t0:.2f}s, "
                   f"encode {t2 - t1:.2f}s, decode {t3 - t2:.2f}s",
@@ -390,17 +484,12 @@ def main():
 
     single = args.kind is not None or args.gib is not None
     kind = args.kind or "zipf"
-    if world > 1 or (use_dist and not single):
-        # one logical stream of --total-gib, cut into contiguous shards
-        gib = args.gib if args.gib is not None else args.total_gib / world
-        steps = args.steps if args.steps is not None else 20
-        warmup = args.warmup if args.warmup is not None else 3
-        scaling = "strong" if args.gib is None else "weak"
-    else:
-        gib = args.gib if args.gib is not None else 1.0
-        steps = args.steps if args.steps is not None else 100
-        warmup = args.warmup if args.warmup is not None else 10
-        scaling = "weak"
+    # one logical stream of --total-gib, cut into contiguous shards: the same
+    # stream whatever the number of GPUs (--gib instead fixes the bytes per GPU)
+    gib = args.gib if args.gib is not None else args.total_gib / world
+    steps = args.steps if args.steps is not None else 20
+    warmup = args.warmup if args.warmup is not None else 3
+    scaling = "strong" if args.gib is None else "weak"
     n = int(gib * GIB)
 
     head = run_workload(args, env, kind, n, steps, warmup)
@@ -437,8 +526,9 @@ def main():
         result["collectives"] = ("gloo on host tensors (rehearsal)" if rehearse else
                                  "RCCL all-gather of the 256-bin histograms (merge + scan in one)")
     for key in ("encode_GBps_uncompressed", "decode_GBps_uncompressed", "histogram_GBps",
-                "kernel_ms", "stage_ms", "hbm_frac", "roofline"):
-        result[key] = head[key]
+                "kernel_ms", "stage_ms", "hbm_frac", "roofline", "decode_nogap"):
+        if key in head:
+            result[key] = head[key]
     if "stream_total_bytes" in head:
         result["config"]["stream_total_bytes"] = head["stream_total_bytes"]
     ok = head["roundtrip_ok"]
@@ -451,14 +541,19 @@ def main():
     if world == 1 and not use_dist and not single and not args.no_extra_configs:
         # the other single-GPU configurations, each with fewer steps as the streams grow
         subs = []
-        for sub_kind, sub_gib, sub_steps in (("uniform", 1, 30), ("geometric", 4, 10),
-                                             ("zipf", 16, 5)):
-            rec = run_workload(args, env, sub_kind, int(sub_gib * GIB), sub_steps, 2)
+        for sub_kind, sub_gib, sub_steps in (("zipf", 1, 100), ("uniform", 1, 30),
+                                             ("geometric", 4, 10)):
+            rec = run_workload(args, env, sub_kind, int(sub_gib * GIB), sub_steps, 3)
             env["last_data"] = None
             torch.cuda.empty_cache()
             ok = ok and rec["roundtrip_ok"]
             subs.append(rec)
         result["configs"] = subs
+
+    if rank == 0 and world == 1 and not use_dist and not single and not args.no_adaptors:
+        rates = adaptor_rates()
+        if rates is not None:
+            result["adaptors"] = rates
 
     if rank == 0:
         line = json.dumps(result)

@@ -69,7 +69,8 @@ class Context:
 
     def kernel_ms(self, kind: int) -> tuple[float, int]:
         """Summed HIP-event duration and launch count of the dominant kernel of the
-        histogram (0), encode (1) or decode (2) calls since the last collection
+        histogram (0), encode (1) or decode (2) calls since the last collection, or
+        of the bare-stream calls' gap_sync_kernel (3) and last walk (4)
         (option "kernel_timing" must be on)."""
         ms = C.c_double()
         cnt = C.c_uint64()

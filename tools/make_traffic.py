@@ -19,11 +19,16 @@ entry = {"source": label}
 for name, v in sorted(json.load(open(summary)).items(), key=lambda kv: kv[0].startswith("hist_batches")):
     if "hbm_read_bytes_corrected" not in v or "hbm_write_bytes" not in v:
         continue
-    key = "histogram" if name.startswith("hist") else ("encode" if name.startswith(("enc_pack", "enc_bytes")) else
-                                                       ("decode" if name.startswith("dec_kernel") else None))
+    key = ("histogram" if name.startswith("hist") else
+           "encode" if name.startswith(("enc_pack", "enc_bytes")) else
+           "decode" if name.startswith("dec_kernel") else
+           "gap_sync" if name.startswith("gap_sync_kernel") else
+           "gap_decode" if name.startswith("gap_decode_kernel") else None)
     if key:
         entry[key] = int(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"])
         entry[key + "_kernel"] = name
+# (a profile of the bare-stream decode only adds its kernels to the workload's entry)
+entry = {**table.get(f"{kind}:{nbytes}:{cs}", {}), **entry} if any(k.startswith("gap_") for k in entry) else entry
 table[f"{kind}:{nbytes}:{cs}"] = entry
 json.dump(table, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps(entry))

@@ -1,5 +1,5 @@
-"""Runs hf_build_gap_array and hf_decode_bare once each on a 1 GiB stream (for
-rocprofv3 --kernel-trace) and times them with the host clock."""
+"""Runs hf_build_gap_array and hf_decode_bare on a stream of [kind] [MiB] (for
+rocprofv3 --kernel-trace / --pmc) and times them with the host clock."""
 import sys
 import time
 import torch
@@ -11,7 +11,7 @@ if os.environ.get("HF_TOOLS_LIB"):  # another build of the library, kept beside 
 from huffman_amd import device as hd, synth
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
-n = 1 << 30
+n = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024) << 20
 data = synth.generate_device(kind, n, seed=2024)
 codes, lens = hd.build_codebook(hd.histogram(data))
 model = hd.DeviceModel(codes, lens)

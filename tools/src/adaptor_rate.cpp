@@ -1,9 +1,11 @@
 // Rates of the streaming adaptors the way the reference's callers drive them:
 // Encoder::write in BUF = 4096-byte pieces (src/lib.rs:68-77) and Decoder::read
-// in 15-byte pieces (examples/decode.rs:55-73).  usage: adaptor_rate [MiB]
+// in 15-byte pieces (examples/decode.rs:55-73).  usage: adaptor_rate [MiB] [--json]
+// (--json: one more line with the four rates, for bench.py)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "hfgpu.hpp"
 
@@ -19,6 +21,8 @@ static double now()
 int main(int argc, char **argv)
 {
     const std::size_t mib = argc > 1 ? std::strtoul(argv[1], nullptr, 10) : 256;
+    const bool json = argc > 2 && !std::strcmp(argv[2], "--json");
+    double rate[4] = {0, 0, 0, 0}; // write tracked, write untracked, read with gap array, read without
     const std::size_t n = mib << 20;
     std::vector<u8> data(n);
     std::uint64_t x = 88172645463325252ull;
@@ -40,6 +44,7 @@ int main(int argc, char **argv)
         std::printf("Encoder::write in %zu-byte calls + flush, write() value %s: %.2f GB/s (%zu -> %zu bytes)\n",
                     BUF, track ? "tracked" : "not tracked", n / (t1 - t0) / 1e9, n,
                     enc.inner.get_ref().size());
+        rate[track ? 0 : 1] = n / (t1 - t0) / 1e9;
         if (track)
             continue;
         for (int with_gap = 1; with_gap >= 0; --with_gap) {
@@ -59,7 +64,13 @@ int main(int argc, char **argv)
                         out == data ? "" : "  MISMATCH");
             if (out != data)
                 return 1;
+            rate[with_gap ? 2 : 3] = n / (t3 - t2) / 1e9;
         }
     }
+    if (json)
+        std::printf("{\"unit\": \"GB/s\", \"bytes\": %zu, \"data\": \"skewed bytes in host memory\", "
+                    "\"write_4096_tracked\": %.3f, \"write_4096_untracked\": %.3f, "
+                    "\"read_15_with_gap_array\": %.3f, \"read_15_bare_stream\": %.3f}\n",
+                    n, rate[0], rate[1], rate[2], rate[3]);
     return 0;
 }
