@@ -104,7 +104,14 @@ impl<R: Read> Decoder<R> {
         if self.gap.is_some() { self.piece_with_gap() } else { self.piece_from_window() }
     }
     fn piece_with_gap(&mut self) -> std::io::Result<bool> {
+        // (taken for the duration of the call so that `self` can be borrowed mutably
+        // below; put back on every way out)
         let g = self.gap.take().unwrap();
+        let r = self.piece_with_gap_of(&g);
+        self.gap = Some(g);
+        r
+    }
+    fn piece_with_gap_of(&mut self, g: &GapArray) -> std::io::Result<bool> {
         let seg_syms = sys::HF_SEG_CHUNKS * g.chunk_syms as u64;
         let (s0, n_segs) = ((self.next_sym / seg_syms) as usize, g.seg_off.len());
         let s1 = n_segs.min(s0 + (PIECE_SYMS / seg_syms).max(1) as usize);
@@ -115,8 +122,10 @@ impl<R: Read> Decoder<R> {
         let first_byte = (g.seg_off[s0] / 8) & !15u64;
         self.drop_before(first_byte);
         self.fill_to((end_bit + 7) / 8 + 16)?;
-        assert!(self.comp_base == first_byte && self.comp_base + self.comp.len() as u64 >= (end_bit + 7) / 8,
-                "the stream ends before the gap array does");
+        if self.comp_base != first_byte || self.comp_base + (self.comp.len() as u64) < (end_bit + 7) / 8 {
+            return Err(std::io::Error::new(std::io::ErrorKind::UnexpectedEof,
+                                           "the stream ends before the gap array does"));
+        }
         self.out.resize(n_piece as usize, 0);
         with_ctx(|ctx| {
             let rc = unsafe {
@@ -128,7 +137,6 @@ impl<R: Read> Decoder<R> {
             check(ctx, rc, "Decoder::read");
         });
         self.next_sym += n_piece;
-        self.gap = Some(g);
         Ok(true)
     }
     fn piece_from_window(&mut self) -> std::io::Result<bool> {

@@ -13,12 +13,14 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <type_traits>
 #include <utility>
 #include <vector>
 
 #include "hfgpu.h"
+
 #include "hfgpu_internal.h"
 
 #include "dev_common.hpp"
@@ -34,6 +36,25 @@
 // hipGetSymbolAddress: hf_ctx_create resolves the address on the context's
 // device and everything else goes through that pointer.
 static __device__ __align__(256) unsigned char scratch[HF_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+
+// One entry per GPU, shared by every context of the process on that GPU: the
+// block's device address and the event its last user recorded behind its last
+// kernel.  A call on another stream waits for that event before its first
+// kernel (neither the wait nor the record allocates); calls on one stream are
+// ordered anyway.  Made by the first hf_ctx_create on the device.
+struct FixedScratch {
+    void *ptr = nullptr;
+    hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+};
+constexpr int FIXED_SCRATCH_DEVICES = 64;
+FixedScratch g_fixed_scratch[FIXED_SCRATCH_DEVICES];
+std::mutex g_fixed_scratch_mutex;
+
+} // namespace
 
 // ===================================================================== host
 
@@ -64,7 +85,8 @@ struct hf_ctx {
     struct Blob {
         void *d;
         size_t bytes;
-        hipStream_t last_stream; // kernels of the model that owned it ran there
+        hipEvent_t free_after; // recorded behind the last kernels of the model that owned it
+                               // (null: they have been waited for)
     };
     std::vector<Blob> blob_cache;
     // pinned staging of the table uploads, used in turn: the upload is an
@@ -284,10 +306,14 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
         std::memcpy(blob + off_pair, pair.data(), pair.size() * sizeof(uint32_t));
     for (size_t i = 0; i < ctx->blob_cache.size(); ++i) {
         if (ctx->blob_cache[i].bytes >= total) {
-            // kernels of the block's previous owner may still be running: on
-            // this stream the copy queues up behind them, another one is waited for
-            if (ctx->blob_cache[i].last_stream != ctx->stream)
-                HF_HIP(ctx, hipStreamSynchronize(ctx->blob_cache[i].last_stream));
+            // kernels of the block's previous owner may still be running: the copy
+            // below is ordered behind the event that owner left (no stream handle is
+            // kept, the stream may be gone by now)
+            if (ctx->blob_cache[i].free_after) {
+                HF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->blob_cache[i].free_after, 0));
+                (void)hipEventDestroy(ctx->blob_cache[i].free_after);
+                ctx->blob_cache[i].free_after = nullptr;
+            }
             mod->d_blob = ctx->blob_cache[i].d;
             mod->blob_bytes = ctx->blob_cache[i].bytes;
             ctx->blob_cache.erase(ctx->blob_cache.begin() + (long)i);
@@ -438,7 +464,19 @@ int hf_ctx_create(int device, hf_ctx **out)
         return HF_ERR_HIP;
     }
     // this device's address of the fixed scratch block (the device is current here)
-    e = hipGetSymbolAddress(&ctx->fixed_scratch, HIP_SYMBOL(scratch));
+    // and the event that orders its users
+    if (device < FIXED_SCRATCH_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_fixed_scratch_mutex);
+        FixedScratch &fs = g_fixed_scratch[device];
+        e = hipSuccess;
+        if (!fs.ptr)
+            e = hipGetSymbolAddress(&fs.ptr, HIP_SYMBOL(scratch));
+        if (e == hipSuccess && !fs.done)
+            e = hipEventCreateWithFlags(&fs.done, hipEventDisableTiming);
+        ctx->fixed_scratch = e == hipSuccess ? fs.ptr : nullptr;
+    } else {
+        e = hipErrorInvalidDevice;
+    }
     if (e != hipSuccess || !ctx->fixed_scratch) {
         (void)hipFree(ctx->d_result);
         (void)hipHostFree(ctx->h_small);
@@ -461,8 +499,11 @@ int hf_ctx_destroy(hf_ctx *ctx)
         (void)hipEventDestroy(ctx->scratch_done);
     if (ctx->arena)
         (void)hipFree(ctx->arena);
-    for (auto &b : ctx->blob_cache)
+    for (auto &b : ctx->blob_cache) {
+        if (b.free_after)
+            (void)hipEventDestroy(b.free_after);
         (void)hipFree(b.d);
+    }
     if (ctx->up_stream)
         (void)hipStreamDestroy(ctx->up_stream);
     if (ctx->down_stream)
@@ -743,7 +784,15 @@ int hf_model_destroy(hf_model *model)
         if (model->foreign)
             (void)hipDeviceSynchronize();
         if (model->ctx->blob_cache.size() < 4) {
-            model->ctx->blob_cache.push_back({model->d_blob, model->blob_bytes, model->use_stream});
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+                hipEventRecord(ev, model->use_stream) != hipSuccess) {
+                if (ev)
+                    (void)hipEventDestroy(ev);
+                ev = nullptr;
+                (void)hipDeviceSynchronize();
+            }
+            model->ctx->blob_cache.push_back({model->d_blob, model->blob_bytes, ev});
         } else {
             (void)hipStreamSynchronize(model->use_stream);
             (void)hipFree(model->d_blob);
@@ -1029,10 +1078,23 @@ int hf_encode_noalloc_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d
                     (unsigned long long)n, (unsigned long long)HF_NOALLOC_MAX_SYMBOLS);
     if ((uintptr_t)d_batch_hist & 15)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_encode_noalloc: d_batch_hist must be 16-byte aligned");
+    // Every context and stream on this GPU shares the one block: a call on another
+    // stream than the block's last user waits for that user's event first.
     // the kernels get the block's device address, never the array's name
-    return encode_launch(ctx, model, d_in, n, lead_bits, d_batch_hist, d_out, out_cap, chunk_syms,
-                         d_chunk_bits, d_seg_off, d_result, ctx->fixed_scratch,
-                         HF_NOALLOC_SCRATCH_BYTES);
+    DeviceGuard on(ctx);
+    std::lock_guard<std::mutex> lock(g_fixed_scratch_mutex);
+    FixedScratch &fs = g_fixed_scratch[ctx->device];
+    if (fs.used && fs.last_stream != ctx->stream)
+        HF_HIP(ctx, hipStreamWaitEvent(ctx->stream, fs.done, 0));
+    const int rc = encode_launch(ctx, model, d_in, n, lead_bits, d_batch_hist, d_out, out_cap,
+                                 chunk_syms, d_chunk_bits, d_seg_off, d_result, ctx->fixed_scratch,
+                                 HF_NOALLOC_SCRATCH_BYTES);
+    // (also after a failed call: some of its kernels may have been queued)
+    if (hipEventRecord(fs.done, ctx->stream) == hipSuccess) {
+        fs.used = true;
+        fs.last_stream = ctx->stream;
+    }
+    return rc;
 }
 
 int hf_encode(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t n,

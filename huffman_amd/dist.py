@@ -122,27 +122,27 @@ def gather_histograms(local_hist: torch.Tensor, dist):
 
 def plan_from_histograms(hists, lens, rank: int) -> ShardPlan:
     """The cross-rank exclusive scan of the shards' bit lengths, computed
-    identically on every rank from the gathered histograms (hf_shard_plan of
-    the C ABI: host arithmetic, no GPU needed)."""
-    import ctypes as C
-
+    identically on every rank from the gathered histograms: row r times the
+    code lengths is shard r's bit length.  Plain host arithmetic (the C ABI's
+    hf_shard_plan does the same sums for bindings in other languages and the
+    tests hold the two against each other), so a rank needs neither the GPU
+    library nor a GPU to plan."""
     import numpy as np
-
-    from ._lib import HF_OK, HfError, lib, u64p
 
     h = np.ascontiguousarray(np.asarray(hists, dtype=np.uint64))
     if h.ndim != 2 or h.shape[1] != 256:
         raise ValueError("expected [world, 256] histograms")
-    ln = np.ascontiguousarray(np.asarray(lens, dtype=np.uint64))
+    ln = np.asarray(lens, dtype=np.uint64).reshape(256)
+    if int(ln.max(initial=0)) > 64:
+        raise ValueError("code length above 64")
     world = h.shape[0]
-    bits = np.zeros(world, dtype=np.uint64)
-    start = np.zeros(world, dtype=np.uint64)
-    rc = lib().hf_shard_plan(h.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), world,
-                             bits.ctypes.data_as(u64p), start.ctypes.data_as(u64p), None, None,
-                             None, None)
-    if rc != HF_OK:
-        raise HfError(rc, "hf_shard_plan")
-    return ShardPlan(rank, world, [int(b) for b in bits], [int(b) for b in start])
+    # (Python integers: a shard of 2^58 symbols times 64 bits does not fit 64 bits)
+    bits = [sum(int(c) * int(l) for c, l in zip(h[r], ln) if c) for r in range(world)]
+    start, acc = [], 0
+    for b in bits:
+        start.append(acc)
+        acc += b
+    return ShardPlan(rank, world, bits, start)
 
 
 def allreduce_histogram(hist: torch.Tensor, dist) -> torch.Tensor:

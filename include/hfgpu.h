@@ -74,7 +74,10 @@ HF_API const char *hf_strerror(int status);
 /* Creates a context on HIP device `device` using the null stream. */
 HF_API int hf_ctx_create(int device, hf_ctx **ctx);
 HF_API int hf_ctx_destroy(hf_ctx *ctx);
-/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).
+ * A stream must stay alive until the models created or last used while it was
+ * bound have been destroyed (hf_model_destroy records an event on it) and the
+ * work queued on it through this library has completed. */
 HF_API int hf_ctx_set_stream(hf_ctx *ctx, void *stream);
 HF_API int hf_ctx_synchronize(hf_ctx *ctx);
 HF_API const char *hf_last_error(const hf_ctx *ctx);
@@ -224,11 +227,16 @@ HF_API int hf_encode_planned_async(hf_ctx *ctx, const hf_model *model, const uin
  * object on every GPU, so the call reaches neither hipMalloc nor hipFree nor
  * any other allocating routine, and it records no kernel timing.
  *   - n above HF_NOALLOC_MAX_SYMBOLS is refused with HF_ERR_UNSUPPORTED.
- *   - Every call on one GPU, from any context, uses that GPU's one block: two
- *     calls that overlap in time on one GPU (different streams, no ordering
- *     between them) race and corrupt each other's streams.  Calls on one
- *     stream, or ordered by events, are fine; the block needs no clearing by
- *     the caller. */
+ *   - Every call on one GPU, from any context of the process, uses that GPU's
+ *     one block.  The library orders them: a call on another stream than the
+ *     block's last user first makes its stream wait for the event that user
+ *     recorded behind its kernels (hipStreamWaitEvent / hipEventRecord on one
+ *     event per GPU; neither allocates), so calls on several streams run one
+ *     after the other instead of corrupting each other.  Calls on one stream
+ *     record the event only.  Inside a stream capture keep to one stream: a
+ *     captured stream cannot wait for an event recorded outside the capture.
+ *     Two PROCESSES on one GPU each have their own block.  The block needs no
+ *     clearing by the caller. */
 #define HF_NOALLOC_MAX_SYMBOLS (1ull << 32)
 #define HF_NOALLOC_SCRATCH_BYTES ((HF_NOALLOC_MAX_SYMBOLS / 16384 + 4) * 8 + 224)
 HF_API int hf_encode_noalloc_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in,

@@ -124,7 +124,7 @@ def test_shard_plan_and_placement_through_the_c_abi(cuts):
     assert first.tolist() == [s // 8 for s in start.tolist()]
     assert last.tolist() == [(s + b + 7) // 8 for s, b in zip(start.tolist(), want_bits)]
     assert total.value == sum(want_bits)
-    # the Python plan is this very function
+    # the Python plan (plain host arithmetic) agrees with the C ABI's
     plan = plan_from_histograms(hists, lens, 0)
     assert plan.bits == want_bits and plan.start_bit == start.tolist()
     want, _ = orc.encode_slice(data, codes, lens)

@@ -78,3 +78,36 @@ def test_noalloc_encode_rejects_inputs_beyond_its_block(dev, orc):
     assert b"limit" in lib().hf_last_error(ctx.handle)
     with pytest.raises(HfError):
         ctx.check(rc)
+
+
+def test_noalloc_encode_on_two_streams_shares_the_block_in_order(dev, orc):
+    """Two streams of one GPU, a call on each without a wait in between: both use
+    the one fixed block, so the second call has to start behind the first one's
+    kernels (the library orders them with a per-GPU event).  Several rounds, the
+    longer input first, so that the first call is still running when the second
+    is queued."""
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cases = []
+    for kind, n, seed in (("zipf", (96 << 20) + 12345, 21), ("geometric", (3 << 20) + 77, 22)):
+        data = synth.generate_host(kind, n, seed=seed)
+        codes, lens = orc.generate_extended_codewords(orc.histogram(data))
+        t = torch.from_numpy(data).cuda()
+        model = dev.DeviceModel(codes, lens)
+        ref = dev.EncodeBuffers(model, n, 64)
+        dev.encode_async(t, model, ref)
+        cases.append((t, model, ref, dev.EncodeBuffers(model, n, 64)))
+    torch.cuda.synchronize()
+    for _ in range(4):
+        for (t, model, ref, got), stream in zip(cases, (s1, s2)):
+            got.data.zero_()
+        torch.cuda.synchronize()
+        for (t, model, ref, got), stream in zip(cases, (s1, s2)):
+            with torch.cuda.stream(stream):
+                dev.encode_noalloc_async(t, model, got)
+        torch.cuda.synchronize()
+        for t, model, ref, got in cases:
+            assert got.result.tolist() == ref.result.tolist()
+            nbytes = (ref.result.tolist()[0] + 7) // 8
+            assert torch.equal(got.data[:nbytes], ref.data[:nbytes])
+            assert torch.equal(got.chunk_bits, ref.chunk_bits)
+            assert torch.equal(got.seg_off, ref.seg_off)
