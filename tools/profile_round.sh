@@ -6,10 +6,17 @@
 # into profiles/.
 tag=${1:-r02}
 ./tools/profile_configs.sh $tag || exit 1
-for cfg in "zipf 1024" "uniform 1024" "geometric 4096" "zipf 16384"; do
+# (2, 4 and 8 GiB: the shards of the multi-GPU runs, for bench.py's roofline.traffic there)
+for cfg in "zipf 1024" "uniform 1024" "geometric 4096" "zipf 16384" "zipf 8192" "zipf 4096" "zipf 2048"; do
   set -- $cfg
   ./tools/pmc.sh gpurun_out/${tag}_pmc_${1}_${2} $1 $2 64 > gpurun_out/${tag}_pmc_${1}_${2}mib_summary.json || { echo "pmc $cfg failed"; exit 1; }
   rm -rf gpurun_out/${tag}_pmc_${1}_${2}
+done
+# the bare-stream decode (gap_sync_kernel, gap_decode_kernel, gap_emit_kernel)
+for cfg in "zipf 1024" "geometric 4096"; do
+  set -- $cfg
+  PROF_SCRIPT=tools/prof_gap.py ./tools/pmc.sh gpurun_out/${tag}_pmc_gap_${1}_${2} $1 $2 64 > gpurun_out/${tag}_pmc_gap_${1}_${2}mib_summary.json || { echo "pmc gap $cfg failed"; exit 1; }
+  rm -rf gpurun_out/${tag}_pmc_gap_${1}_${2}
 done
 python3 - <<PY
 import json, glob
