@@ -1428,7 +1428,7 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
     if (g.n_wg >= (1ull << 31))
         return fail(ctx, HF_ERR_BAD_ARG, "hf_build_gap_array: stream too long");
 
-    // scratch: start_off | exit_off | cnt | wg_in | wg_used | changed | wg_base | start32
+    // scratch: start_off | exit_off | cnt | wg_in | wg_used | changed | wg_base | start32 | blk_total
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -1438,6 +1438,8 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
     const size_t o_start = take(g.n_sub), o_exit = take(g.n_sub), o_cnt = take(g.n_sub * 4);
     const size_t o_in = take(g.n_wg * 4), o_used = take(g.n_wg * 4), o_chg = take(4);
     const size_t o_base = take((g.n_wg + 1) * 8), o_s32 = take(gaps ? (g.n_chunks + 1) * 4 : 4);
+    const uint32_t scan_blocks = (uint32_t)((g.n_wg + GAP_SCAN_BLOCK - 1) / GAP_SCAN_BLOCK);
+    const size_t o_blk = take((size_t)scan_blocks * 4);
     rc = scratch_acquire(ctx, off);
     if (rc != HF_OK)
         return rc;
@@ -1449,6 +1451,7 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
     g.wg_used = reinterpret_cast<uint32_t *>(b + o_used);
     g.changed = reinterpret_cast<uint32_t *>(b + o_chg);
     g.wg_base = reinterpret_cast<uint64_t *>(b + o_base);
+    g.blk_total = reinterpret_cast<uint32_t *>(b + o_blk);
     g.start32 = reinterpret_cast<uint32_t *>(b + o_s32);
     HF_HIP(ctx, hipMemsetAsync(ctx->d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));
 
@@ -1487,7 +1490,8 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
         HF_HIP(ctx, hipMemsetAsync(g.changed, 0, 4, ctx->stream));
         hipLaunchKernelGGL(gap_verify_kernel, one_per_wg, dim3(GAP_THREADS), 0, ctx->stream, g);
         hipLaunchKernelGGL(gap_wgsum_kernel, wgs, dim3(GAP_THREADS), 0, ctx->stream, g);
-        hipLaunchKernelGGL(gap_scan_kernel, dim3(1), dim3(GAP_THREADS), 0, ctx->stream, g);
+        hipLaunchKernelGGL(gap_scan_local_kernel, dim3(scan_blocks), dim3(GAP_THREADS), 0, ctx->stream, g);
+        hipLaunchKernelGGL(gap_scan_add_kernel, dim3(scan_blocks), dim3(GAP_THREADS), 0, ctx->stream, g);
         uint64_t *h = ctx->h_small; // [0..3] result block, [4] changed, [5] symbols in the stream
         if (whole) {
             HF_HIP(ctx, hipMemsetAsync(ctx->d_result, 0, HF_RES_WORDS * sizeof(uint64_t), ctx->stream));

@@ -80,6 +80,7 @@ struct GapParams {
     uint32_t *wg_used;   // [n_wg] first start its results were computed with
     uint32_t *changed;   // set by gap_verify_kernel when some wg_in != wg_used
     uint64_t *wg_base;   // [n_wg + 1] symbols before each workgroup (after the scan)
+    uint32_t *blk_total; // [ceil(n_wg / GAP_SCAN_BLOCK)] symbols per block of work-groups (the scan's second level)
     uint32_t *start32;   // [n_chunks + 1] low 32 bits of the chunk start bits
     uint64_t n_chunks;
     uint32_t first;      // first launch: no earlier results, first starts assumed from the overlap lane
@@ -325,33 +326,60 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_wgsum_kernel(GapParams g)
         g.wg_base[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(GAP_THREADS) void gap_scan_kernel(GapParams g)
+// Exclusive scan of the work-groups' symbol counts (wg_base, in place; the total
+// goes behind the last entry) in two launches of many work-groups: each scans a
+// block of GAP_SCAN_BLOCK counts on its own and leaves the block's total, then
+// each adds what the blocks before it hold.  (A block's counts sum to less than
+// 2^32: 4096 work-groups of at most 255 x 512 codes.)
+constexpr uint32_t GAP_SCAN_PER = 16; // counts per lane
+constexpr uint32_t GAP_SCAN_BLOCK = GAP_THREADS * GAP_SCAN_PER;
+
+__global__ __launch_bounds__(GAP_THREADS) void gap_scan_local_kernel(GapParams g)
+{
+    __shared__ uint32_t s_wave[GAP_THREADS / 64];
+    const uint64_t lo = (uint64_t)blockIdx.x * GAP_SCAN_BLOCK + threadIdx.x * GAP_SCAN_PER;
+    uint32_t v[GAP_SCAN_PER];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < GAP_SCAN_PER; ++k) {
+        v[k] = lo + k < g.n_wg ? (uint32_t)g.wg_base[lo + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan256(sum, s_wave, total);
+#pragma unroll
+    for (uint32_t k = 0; k < GAP_SCAN_PER; ++k) {
+        if (lo + k < g.n_wg)
+            g.wg_base[lo + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0)
+        g.blk_total[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(GAP_THREADS) void gap_scan_add_kernel(GapParams g)
 {
     __shared__ uint64_t s_part[GAP_THREADS];
-    // every thread owns a contiguous run of workgroups
-    const uint64_t per = (g.n_wg + GAP_THREADS - 1) / GAP_THREADS;
-    const uint64_t lo = min(g.n_wg, per * threadIdx.x), hi = min(g.n_wg, lo + per);
-    uint64_t sum = 0;
-    for (uint64_t w = lo; w < hi; ++w)
-        sum += g.wg_base[w];
-    s_part[threadIdx.x] = sum;
+    uint64_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += GAP_THREADS)
+        part += g.blk_total[b];
+    s_part[threadIdx.x] = part;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (uint32_t k = 0; k < GAP_THREADS; ++k) {
-            const uint64_t v = s_part[k];
-            s_part[k] = run;
-            run += v;
-        }
-        g.wg_base[g.n_wg] = run;
+    for (uint32_t step = GAP_THREADS / 2; step > 0; step >>= 1) {
+        if (threadIdx.x < step)
+            s_part[threadIdx.x] += s_part[threadIdx.x + step];
+        __syncthreads();
     }
-    __syncthreads();
-    uint64_t run = s_part[threadIdx.x];
-    for (uint64_t w = lo; w < hi; ++w) {
-        const uint64_t v = g.wg_base[w];
-        g.wg_base[w] = run;
-        run += v;
+    const uint64_t base = s_part[0];
+    const uint64_t lo = (uint64_t)blockIdx.x * GAP_SCAN_BLOCK + threadIdx.x * GAP_SCAN_PER;
+    if (base) {
+#pragma unroll
+        for (uint32_t k = 0; k < GAP_SCAN_PER; ++k)
+            if (lo + k < g.n_wg)
+                g.wg_base[lo + k] += base;
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        g.wg_base[g.n_wg] = base + g.blk_total[blockIdx.x];
 }
 
 // What the last walk of a lane starts from: its sub-sequence, the number of
