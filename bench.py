@@ -341,10 +341,10 @@ def bare_decode(ctx, hd, torch, bufs, model, C: int, n: int, out, data, kind: st
                               "gap_decode_kernel": walk_launches / calls},
     }
     for name, key in (("gap_sync_kernel", "gap_sync"), ("gap_decode_kernel", "gap_decode")):
-        traffic, source = pmc_traffic(kind, n, cs, key)
+        traffic, _ = pmc_traffic(kind, n, cs, key)
         if traffic is not None:
             rec.setdefault("traffic", {})[name] = traffic
-            rec["traffic_source"] = source
+            rec["traffic_source"] = pmc_traffic(kind, n, cs, "gap_source")[0]
     return rec
 
 
