@@ -312,13 +312,15 @@ bool is_complete_prefix_code(const uint64_t *keys, const uint8_t *klens, uint64_
     return true;
 }
 
-bool build_pair_lut(const DecodeLut &lut, double max_slow, std::vector<uint32_t> *pair)
+bool build_pair_lut(const DecodeLut &lut, double max_slow, const uint64_t *keys, const uint8_t *syms,
+                    const uint8_t *klens, uint64_t m, uint32_t max_sub, std::vector<uint32_t> *pair)
 {
     const uint32_t w = lut.w1;
     const uint32_t n = 1u << w;
     const uint32_t slow_limit = (uint32_t)(max_slow * (double)n);
     pair->assign(n, HF_PAIR_SLOW | HF_PAIR_UNRESOLVED);
     uint32_t slow = 0;
+    std::vector<uint32_t> slow_at;
     for (uint32_t x = 0; x < n; ++x) {
         if (slow > slow_limit) { // most models are out after a few dozen indices
             pair->clear();
@@ -328,6 +330,7 @@ bool build_pair_lut(const DecodeLut &lut, double max_slow, std::vector<uint32_t>
         const uint32_t l0 = HF_LUT_LEN(e0);
         if ((e0 & HF_LUT_ESC) || l0 == 0 || l0 > w) {
             ++slow;
+            slow_at.push_back(x);
             continue;
         }
         // the bits behind the first code, zero filled: a second code that ends
@@ -337,13 +340,51 @@ bool build_pair_lut(const DecodeLut &lut, double max_slow, std::vector<uint32_t>
         if (l0 == w || (e1 & HF_LUT_ESC) || l1 == 0 || l0 + l1 > w) {
             (*pair)[x] = HF_PAIR_SLOW | (HF_LUT_SYM(e0) << 8) | l0; // first symbol only
             ++slow;
+            slow_at.push_back(x);
             continue;
         }
         (*pair)[x] = (HF_LUT_SYM(e0) << 8) | (HF_LUT_SYM(e1) << 16) | (l0 + l1);
     }
-    if (slow > slow_limit)
+    if (slow > slow_limit) {
         pair->clear();
-    return slow <= slow_limit;
+        return false;
+    }
+    // Second level: the slow indices each get a table over the next
+    // HF_PAIR_W2 bits of the window, filled the same way from the w +
+    // HF_PAIR_W2 bits that are then known (the code at the head of a window
+    // comes from the key search; it is the real one when it ends inside the
+    // known bits, the table being a complete prefix code).  The first-level
+    // entry then only names its table.
+    const uint32_t s = lut.sentinel;
+    auto head = [&](uint64_t win, uint32_t *sym, uint32_t *len) { // win: left-aligned 64 bits
+        const int64_t k = predecessor(keys, m, win >> (64 - s));
+        if (k < 0)
+            return false;
+        *sym = syms[k];
+        *len = klens[k];
+        return *len != 0;
+    };
+    const uint32_t known = w + HF_PAIR_W2;
+    uint32_t n_sub = 0;
+    for (uint32_t x : slow_at) {
+        if (n_sub >= std::min(max_sub, HF_PAIR_MAX_SUB) || known > 32)
+            break;
+        const size_t base = pair->size();
+        pair->resize(base + ((size_t)1 << HF_PAIR_W2), HF_PAIR_SLOW | HF_PAIR_UNRESOLVED);
+        for (uint32_t y = 0; y < (1u << HF_PAIR_W2); ++y) {
+            const uint64_t win = (uint64_t)((x << HF_PAIR_W2) | y) << (64 - known);
+            uint32_t s0, l0, s1, l1;
+            if (!head(win, &s0, &l0) || l0 > known)
+                continue;
+            if (l0 < known && head(win << l0, &s1, &l1) && l0 + l1 <= known)
+                (*pair)[base + y] = (s0 << 8) | (s1 << 16) | (l0 + l1);
+            else if (l0 <= 63)
+                (*pair)[base + y] = HF_PAIR_SLOW | (s0 << 8) | l0;
+        }
+        (*pair)[x] = HF_PAIR_SLOW | HF_PAIR_SUB | (n_sub << 8);
+        ++n_sub;
+    }
+    return true;
 }
 
 bool prefer_padded_image(double mean_bits, double sd_bits)

@@ -275,7 +275,8 @@ int upload_model(hf_ctx *ctx, hf_model *mod, const uint64_t *enc_tab /*256 or nu
     std::vector<uint32_t> pair;
     const bool complete = hf::is_complete_prefix_code(keys, klens, m, lut.sentinel);
     if (lut.w1 >= 6 && complete)
-        (void)hf::build_pair_lut(lut, 0.01, &pair);
+        (void)hf::build_pair_lut(lut, 0.01, keys, syms, klens, m,
+                                 (ctx->debug & 2048) ? 0u : HF_PAIR_MAX_SUB, &pair);
     const size_t off_pair = align_up(off_klens + 256, 16);
     const size_t total = off_pair + pair.size() * sizeof(uint32_t);
     hf_ctx::Pinned &ps = ctx->pinned[ctx->pinned_next++ % 4];
@@ -584,7 +585,7 @@ int hf_ctx_set_option(hf_ctx *ctx, const char *name, int64_t value)
         ctx->kernel_timing = value != 0;
     else if (!std::strcmp(name, "dec_trace")) // device address, 128 bytes per segment; 0 = off
         ctx->dec_trace = reinterpret_cast<uint64_t *>((uintptr_t)value);
-    else if (!std::strcmp(name, "debug") && value >= 0 && value < 1024)
+    else if (!std::strcmp(name, "debug") && value >= 0 && value < 4096)
         ctx->debug = (int)value;
     else
         return fail(ctx, HF_ERR_BAD_ARG, "unknown option or value out of range: %s", name);
@@ -1302,8 +1303,19 @@ int hf_decode_async(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uin
             kern = spr == 4 ? dec_kernel<4, false>
                             : (spr == 2 ? dec_kernel<2, false> : dec_kernel<1, false>);
     }
-    const uint32_t grid = (uint32_t)n_segs, threads = DEC_THREADS;
+    uint32_t grid = (uint32_t)n_segs;
+    const uint32_t threads = DEC_THREADS;
     ctx->decode_kernel = p.img_cap ? (pairs ? "dec_kernel_reg (pairs)" : "dec_kernel_reg") : "dec_kernel";
+    // pair tables, plain image, aligned buffers: two segments per work-group, two
+    // look-up chains per lane (the tables are staged once for both)
+    if (p.img_cap && pairs && !swz && p.in_aligned16 && p.out_aligned16 && n_segs >= 2 &&
+        !(ctx->debug & 1024)) {
+        kern = kk >= 16 ? dec_kernel_pair2<16> : (kk >= 8 ? dec_kernel_pair2<8> : dec_kernel_pair2<6>);
+        p.istg_words = p.img_cap + 4; // (plain image: no padding slots)
+        lds = lut_bytes + (size_t)model->pair_entries * 4 + (size_t)(2 * p.istg_words + 8) * 4;
+        grid = (uint32_t)((n_segs + 1) / 2);
+        ctx->decode_kernel = "dec_kernel_pair2";
+    }
     if (lds > 160 * 1024 - 64)
         return fail(ctx, HF_ERR_BAD_ARG, "hf_decode: chunk_syms %u needs %zu bytes of LDS",
                     chunk_syms, lds);

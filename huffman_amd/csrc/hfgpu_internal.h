@@ -82,9 +82,18 @@ bool is_complete_prefix_code(const uint64_t *keys, const uint8_t *klens, uint64_
 // well-compressed stream every index is about equally likely, so the slow
 // fraction of the index space is the probability that a lookup needs the
 // fix-up.  Returns false, with `pair` empty, when it exceeds `max_slow`.
+// Behind the 1 << w1 first-level entries follow up to HF_PAIR_MAX_SUB
+// second-level tables of 1 << HF_PAIR_W2 entries, one per slow index, over the
+// next HF_PAIR_W2 bits of the window: entries of the same form for the w1 +
+// HF_PAIR_W2 bits known there.  A slow first-level entry that has such a
+// table carries HF_PAIR_SUB and the table's number << 8 instead of a symbol.
 #define HF_PAIR_SLOW 0x80000000u
 #define HF_PAIR_UNRESOLVED 0x40000000u
-bool build_pair_lut(const DecodeLut &lut, double max_slow, std::vector<uint32_t> *pair);
+#define HF_PAIR_SUB 0x20000000u
+#define HF_PAIR_W2 6u
+#define HF_PAIR_MAX_SUB 32u
+bool build_pair_lut(const DecodeLut &lut, double max_slow, const uint64_t *keys, const uint8_t *syms,
+                    const uint8_t *klens, uint64_t m, uint32_t max_sub, std::vector<uint32_t> *pair);
 // Layout of the decoder's LDS image of the stream.  Lane l of a wave starts
 // reading near word l * mean_bits / 32 (chunk l of the segment), and 32 lanes
 // are served per LDS cycle, one word per bank (word index mod 32): chunk sizes

@@ -51,7 +51,7 @@ struct DecParams {
     const uint8_t *klens;
     uint32_t m;
     const uint32_t *pair;  // two-symbol table over the first-level index (PAIR kernels), or null
-    uint32_t pair_entries; // 1 << w1 when pair is set
+    uint32_t pair_entries; // (1 << w1) + second-level tables (HF_PAIR_W2 bits each) when pair is set
     uint32_t istg_words;   // LDS words reserved for the stream image (padding slots included)
     uint32_t img_cap;      // dec_kernel_reg: stream words the image holds
     uint32_t in_aligned16;
@@ -357,9 +357,18 @@ __device__ inline uint32_t dec_escape_window(uint64_t win, uint32_t e, const uin
 // len1).  Two codes that do not fit the 64-bit window together mark the lane
 // dirty instead (their length is reported as 0).
 __device__ inline uint32_t dec_pair_slow(uint64_t win, uint32_t e, const uint16_t *s_lut,
-                                         const DecParams &p, bool &bad, bool &dirty)
+                                         const uint32_t *s_pair, const DecParams &p, bool &bad,
+                                         bool &dirty)
 {
     const uint32_t shift = 32 - p.w1;
+    if (e & HF_PAIR_SUB) {
+        // the index's second-level table over the next HF_PAIR_W2 bits: nearly always
+        // a complete pair (of up to w1 + HF_PAIR_W2 bits)
+        const uint32_t next = ((uint32_t)(win >> 32) << p.w1) >> (32 - HF_PAIR_W2);
+        e = s_pair[(1u << p.w1) + (((e >> 8) & 0xffu) << HF_PAIR_W2) + next];
+        if ((int32_t)e >= 0)
+            return e;
+    }
     uint32_t sym0 = (e >> 8) & 0xffu, l0 = e & 0x7fu;
     if (e & HF_PAIR_UNRESOLVED) {
         uint32_t e0 = s_lut[(uint32_t)(win >> 32) >> shift];
@@ -588,9 +597,10 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
             uint64_t win = ((uint64_t)hi << 32) | lo;
             // The low byte of the sum of the entries is the sum of their lengths
             // as long as that stays below 256: a pair from the table has at most
-            // w1 bits (8 x 11), a completed one up to 64.  Completed pairs that
-            // take the window past its 64 bits mark the lane dirty on the spot,
-            // so the byte is exact (at most 64 + 88) whenever it is used.
+            // w1 bits, from a second-level table w1 + 6 (8 x 17), a completed one
+            // up to 64.  Completed pairs that take the window past its 64 bits
+            // mark the lane dirty on the spot, so the byte is exact (at most
+            // 64 + 136) whenever it is used.
             uint32_t esum = 0;
 #pragma unroll
             for (int k = 0; k < K; k += 2) {
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                 if (j < CS) {
                     uint32_t e = s_pair[(uint32_t)(win >> 32) >> shift];
                     if (__builtin_expect((int32_t)e < 0, 0)) {
-                        e = dec_pair_slow(win, e, s_lut, p, bad, dirty);
+                        e = dec_pair_slow(win, e, s_lut, s_pair, p, bad, dirty);
                         dirty = dirty || (esum & 0xffu) + (e & 0x7fu) > 64u;
                     }
                     win <<= (e & 63u); // the entry is its own shift amount
@@ -756,6 +766,266 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                 atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS],
                          (unsigned long long)HF_FLAG_DECODE);
         }
+    }
+}
+
+// Two segments per work-group, two look-up chains per lane (pair tables, 64-symbol
+// chunks, plain image, 16-byte aligned buffers): lane l decodes chunk l of both
+// segments in one interleaved loop.  The pair decoder is bound by the length of
+// its chain of dependent LDS look-ups with all eight wave slots of a SIMD taken;
+// a second, independent chain per lane is the parallelism that is left, and the
+// tables are staged once for two segments.  Everything else -- window rebuild
+// every K codes, completion of pairs the table cannot hold, dirty lanes, quad
+// transpose before the stores -- is dec_kernel_reg's, per chain.
+__device__ __forceinline__ void dec_store_chunk64(uint32_t (&U)[16], uint64_t c, bool whole, const DecParams &p)
+{
+    const unsigned long long whole_mask = __ballot(whole);
+    const uint32_t r = threadIdx.x & 3u;
+    const bool odd1 = (r & 1u) != 0, odd2 = (r & 2u) != 0;
+    const uint32_t quad0 = threadIdx.x & 60u;
+#pragma unroll
+    for (int stage = 0; stage < 2; ++stage) {
+        const bool odd = stage == 0 ? odd1 : odd2;
+        const int step = stage == 0 ? 1 : 2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u & step)
+                continue;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t a = U[4 * u + d], b = U[4 * (u + step) + d];
+                const uint32_t give = odd ? a : b;
+                const uint32_t recv = (uint32_t)(stage == 0
+                    ? __builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xf, 0xf, false)
+                    : __builtin_amdgcn_update_dpp(0, (int)give, 0x4E, 0xf, 0xf, false));
+                U[4 * u + d] = odd ? recv : a;
+                U[4 * (u + step) + d] = odd ? b : recv;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if ((whole_mask >> (quad0 + i)) & 1ull) {
+            const uint64_t ci = c - r + i;
+            *reinterpret_cast<uint4 *>(p.out + ci * 64u + r * 16u) =
+                make_uint4(U[4 * i + 0], U[4 * i + 1], U[4 * i + 2], U[4 * i + 3]);
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(DEC_THREADS) void dec_kernel_pair2(DecParams p)
+{
+    constexpr int CS = 64;
+    static_assert(K % 2 == 0, "pairs");
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t lut_bytes = (p.lut_entries * 2u + 15u) & ~15u;
+    const uint32_t pair_bytes = p.pair_entries * 4u;
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
+    const uint32_t *s_pair = reinterpret_cast<const uint32_t *>(smem + lut_bytes);
+    uint32_t *img0 = reinterpret_cast<uint32_t *>(smem + lut_bytes + pair_bytes);
+    uint32_t *img1 = img0 + p.istg_words;
+    uint32_t *s_wave = img1 + p.istg_words; // 8 words
+
+    const uint64_t last_seg = (p.n_chunks - 1) / HF_SEG_CHUNKS;
+    const uint64_t segA = 2ull * blockIdx.x;
+    const bool haveB = segA + 1 <= last_seg;
+    const uint64_t segB = haveB ? segA + 1 : segA;
+    const uint64_t cA = segA * HF_SEG_CHUNKS + threadIdx.x, cB = segB * HF_SEG_CHUNKS + threadIdx.x;
+    const bool validA = cA < p.n_chunks, validB = haveB && cB < p.n_chunks;
+    const uint32_t cbA = validA ? p.chunk_bits[cA] : 0u;
+    const uint32_t cbB = validB ? p.chunk_bits[cB] : 0u;
+    const uint4 *lut16 = reinterpret_cast<const uint4 *>(p.lut);
+    const uint4 *pair16 = reinterpret_cast<const uint4 *>(p.pair);
+    const uint32_t lut_units = lut_bytes / 16, pair_units = pair_bytes / 16;
+    const uint4 lut0 = lut16[min(threadIdx.x, lut_units - 1u)];
+    const uint4 pr0 = pair16[min(threadIdx.x, pair_units - 1u)];
+    const uint4 pr1 = pair16[min(threadIdx.x + DEC_THREADS, pair_units - 1u)];
+    const uint64_t so0 = p.seg_off[segA], so1 = p.seg_off[segB];
+    const uint64_t so2 = p.seg_off[min(segB + 1, last_seg)];
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t IMG_CAP = p.img_cap;
+    const uint64_t whole = p.in_bytes >> 4;
+    const uint4 *in16 = reinterpret_cast<const uint4 *>(p.in);
+    const uint64_t startA = so0 - p.bit_base, startB = so1 - p.bit_base;
+    const uint64_t ubA = startA >> 7, ubB = startB >> 7;
+    const uint32_t sloA = (uint32_t)(startA & 127u), sloB = (uint32_t)(startB & 127u);
+    // the spans are known from consecutive segment offsets: their first units are
+    // requested before the scans (two 16-byte units per lane and segment)
+    constexpr int EARLY = 2;
+    uint32_t neA = 0, neB = 0;
+    if (haveB && so1 - so0 <= (uint64_t)IMG_CAP * 32u) {
+        neA = (uint32_t)((sloA + (so1 - so0) + 127u) / 128u) + 1u;
+        if (neA * 4u > IMG_CAP || ubA + neA > whole)
+            neA = 0;
+    }
+    if (haveB && segB < last_seg && so2 - so1 <= (uint64_t)IMG_CAP * 32u) {
+        neB = (uint32_t)((sloB + (so2 - so1) + 127u) / 128u) + 1u;
+        if (neB * 4u > IMG_CAP || ubB + neB > whole)
+            neB = 0;
+    }
+    uint4 stA[EARLY], stB[EARLY];
+    {
+        const uint4 *fromA = neA ? in16 + ubA : lut16, *fromB = neB ? in16 + ubB : lut16;
+        const uint32_t topA = neA ? neA - 1u : 0u, topB = neB ? neB - 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < EARLY; ++k) {
+            stA[k] = fromA[min(threadIdx.x + k * DEC_THREADS, topA)];
+            stB[k] = fromB[min(threadIdx.x + k * DEC_THREADS, topB)];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        if (threadIdx.x < lut_units)
+            dst[threadIdx.x] = lut0;
+        for (uint32_t i = threadIdx.x + DEC_THREADS; i < lut_units; i += DEC_THREADS)
+            dst[i] = lut16[i];
+        uint4 *pdst = reinterpret_cast<uint4 *>(smem + lut_bytes);
+        if (threadIdx.x < pair_units)
+            pdst[threadIdx.x] = pr0;
+        if (threadIdx.x + DEC_THREADS < pair_units)
+            pdst[threadIdx.x + DEC_THREADS] = pr1;
+        for (uint32_t i = threadIdx.x + 2 * DEC_THREADS; i < pair_units; i += DEC_THREADS)
+            pdst[i] = pair16[i];
+    }
+    uint32_t totalA, totalB;
+    const uint32_t exclA = block_excl_scan256(cbA, s_wave, totalA);
+    const uint32_t exclB = block_excl_scan256(cbB, s_wave + 4, totalB);
+    const uint32_t nuA = (sloA + totalA + 127u) / 128u + 1u, nuB = (sloB + totalB + 127u) / 128u + 1u;
+    const bool ldsA = nuA * 4u <= IMG_CAP, ldsB = haveB && nuB * 4u <= IMG_CAP;
+    auto stage = [&](uint32_t *img, uint64_t ubase, uint32_t nunits, uint32_t n_early, const uint4 (&st)[EARLY]) {
+        const bool early_ok = nunits <= n_early;
+        if (early_ok) {
+#pragma unroll
+            for (int k = 0; k < EARLY; ++k) {
+                const uint32_t i = threadIdx.x + k * DEC_THREADS;
+                if (i < nunits) {
+                    uint4 v = st[k];
+                    v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
+                    reinterpret_cast<uint4 *>(img)[i] = v;
+                }
+            }
+        }
+        for (uint32_t i = threadIdx.x + (early_ok ? EARLY * DEC_THREADS : 0); i < nunits; i += DEC_THREADS) {
+            const uint64_t u = ubase + i;
+            uint4 v;
+            if (u < whole) {
+                v = in16[u];
+                v.x = bswap32(v.x), v.y = bswap32(v.y), v.z = bswap32(v.z), v.w = bswap32(v.w);
+            } else {
+                v.x = dec_load_word(p.in, p.in_bytes, u * 4 + 0);
+                v.y = dec_load_word(p.in, p.in_bytes, u * 4 + 1);
+                v.z = dec_load_word(p.in, p.in_bytes, u * 4 + 2);
+                v.w = dec_load_word(p.in, p.in_bytes, u * 4 + 3);
+            }
+            reinterpret_cast<uint4 *>(img)[i] = v;
+        }
+    };
+    if (ldsA)
+        stage(img0, ubA, nuA, neA, stA);
+    if (ldsB)
+        stage(img1, ubB, nuB, neB, stB);
+    __syncthreads();
+
+    const uint64_t symA = cA * CS, symB = cB * CS;
+    const uint32_t cntA = validA ? (uint32_t)min((uint64_t)CS, p.n_out - symA) : 0u;
+    const uint32_t cntB = validB ? (uint32_t)min((uint64_t)CS, p.n_out - symB) : 0u;
+    const bool fastA = ldsA && cntA == (uint32_t)CS, fastB = ldsB && cntB == (uint32_t)CS;
+    uint32_t outA[CS / 4], outB[CS / 4];
+#pragma unroll
+    for (int i = 0; i < CS / 4; ++i)
+        outA[i] = 0, outB[i] = 0;
+    bool badA = false, badB = false, dirtyA = false, dirtyB = false;
+    {
+        // (a chain without a whole chunk in the image walks from bit 0 of its image:
+        // whatever it reads there, its look-ups stay inside the tables and its
+        // results are dropped)
+        uint32_t posA = fastA ? sloA + exclA : 0u, posB = fastB ? sloB + exclB : 0u;
+        const uint32_t shift = 32 - p.w1;
+#pragma unroll
+        for (int g = 0; g < CS; g += K) {
+            uint64_t winA, winB;
+            {
+                const uint32_t *w = img0 + (posA >> 5);
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+                const uint32_t sh = 32u - (posA & 31u);
+                const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
+                const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
+                winA = ((uint64_t)hi << 32) | lo;
+            }
+            {
+                const uint32_t *w = img1 + (posB >> 5);
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+                const uint32_t sh = 32u - (posB & 31u);
+                const uint32_t hi = (uint32_t)((((uint64_t)w0 << 32) | w1) >> sh);
+                const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w2) >> sh);
+                winB = ((uint64_t)hi << 32) | lo;
+            }
+            uint32_t esA = 0, esB = 0;
+#pragma unroll
+            for (int k = 0; k < K; k += 2) {
+                const int j = g + k;
+                if (j < CS) {
+                    uint32_t eA = s_pair[(uint32_t)(winA >> 32) >> shift];
+                    uint32_t eB = s_pair[(uint32_t)(winB >> 32) >> shift];
+                    if (__builtin_expect((int32_t)eA < 0, 0)) {
+                        eA = dec_pair_slow(winA, eA, s_lut, s_pair, p, badA, dirtyA);
+                        dirtyA = dirtyA || (esA & 0xffu) + (eA & 0x7fu) > 64u;
+                    }
+                    if (__builtin_expect((int32_t)eB < 0, 0)) {
+                        eB = dec_pair_slow(winB, eB, s_lut, s_pair, p, badB, dirtyB);
+                        dirtyB = dirtyB || (esB & 0xffu) + (eB & 0x7fu) > 64u;
+                    }
+                    winA <<= (eA & 63u);
+                    winB <<= (eB & 63u);
+                    esA += eA;
+                    esB += eB;
+                    const uint32_t sel = (j & 2) ? 0x06050100u : 0x03020605u;
+                    outA[j >> 2] = __builtin_amdgcn_perm(eA, outA[j >> 2], sel);
+                    outB[j >> 2] = __builtin_amdgcn_perm(eB, outB[j >> 2], sel);
+                }
+            }
+            const uint32_t usedA = esA & 0xffu, usedB = esB & 0xffu;
+            // (a chain that is not decoding stays inside its image: it starts over)
+            posA = fastA ? posA + usedA : 0u;
+            posB = fastB ? posB + usedB : 0u;
+            dirtyA = dirtyA || usedA > 64u;
+            dirtyB = dirtyB || usedB > 64u;
+        }
+    }
+    dirtyA = dirtyA && fastA;
+    dirtyB = dirtyB && fastB;
+    // ragged chunks and segments too dense for the image: bytes straight to global memory
+    auto rolled = [&](uint64_t ubase, uint32_t start, uint64_t sym0, uint32_t cnt, bool &bad) {
+        GlobalWords src{p.in, p.in_bytes, ubase * 4};
+        BitReader<GlobalWords> br(src, start);
+        const uint32_t sh = 32 - p.w1;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            br.refill();
+            p.out[sym0 + i] = (uint8_t)dec_symbol<GlobalWords, true>(br, s_lut, sh, p, bad);
+        }
+    };
+    if (cntA && !fastA) {
+        badA = false;
+        rolled(ubA, sloA + exclA, symA, cntA, badA);
+    }
+    if (cntB && !fastB) {
+        badB = false;
+        rolled(ubB, sloB + exclB, symB, cntB, badB);
+    }
+    if ((badA && cntA && !dirtyA) || (badB && cntB && !dirtyB))
+        atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
+    dec_store_chunk64(outA, cA, fastA && !dirtyA, p);
+    dec_store_chunk64(outB, cB, fastB && !dirtyB, p);
+    if (dirtyA || dirtyB) {
+        bool bad2 = false;
+        if (dirtyA)
+            rolled(ubA, sloA + exclA, symA, cntA, bad2);
+        if (dirtyB)
+            rolled(ubB, sloB + exclB, symB, cntB, bad2);
+        if (bad2)
+            atomicOr((unsigned long long *)&p.result[HF_RES_FLAGS], (unsigned long long)HF_FLAG_DECODE);
     }
 }
 

@@ -117,7 +117,7 @@ HF_API int hf_ctx_kernel_ms(hf_ctx *ctx, int kind, double *sum_ms, uint64_t *lau
  * measuring aid without counterpart in the reference. */
 HF_API const char *hf_ctx_encode_kernel(const hf_ctx *ctx);
 /* The same for the context's last hf_decode / hf_decode_async call
- * ("dec_kernel_reg (pairs)", "dec_kernel_reg", "dec_kernel"). */
+ * ("dec_kernel_pair2", "dec_kernel_reg (pairs)", "dec_kernel_reg", "dec_kernel"). */
 HF_API const char *hf_ctx_decode_kernel(const hf_ctx *ctx);
 
 /* -------------------------------------------------------- L0: src/stats.rs */

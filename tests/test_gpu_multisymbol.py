@@ -129,3 +129,37 @@ def test_many_segments_per_cu_and_an_odd_segment_count(dev, orc):
     stream = enc.stream()[: head].cpu().numpy()
     want = orc.decode_read(stream, codes, lens, head // 2)
     assert np.array_equal(out[: head // 2].cpu().numpy(), want[: head // 2])
+
+
+@pytest.mark.parametrize("n", [2 * 16384, 3 * 16384, 5 * 16384 + 1, 11 * 16384 + 9001, 64 * 16384 - 63])
+def test_two_segments_per_work_group_against_one(dev, orc, n):
+    """Steep complete codes with aligned buffers go through the decoder that gives a
+    work-group two segments and every lane two chunks: even and odd segment counts,
+    a ragged last chunk in either half, against the one-segment kernel (context
+    option "debug" 1024) and the oracle.  The data mixes in the rarest symbols far
+    more often than the codebook expects, so pairs the tables cannot hold, second-
+    level tables, dirty lanes and segments too dense for the image all occur."""
+    rng = np.random.default_rng(n)
+    base = synth.generate_host("geometric", 1 << 22, seed=3)
+    codes, lens = orc.generate_extended_codewords(orc.histogram(base))
+    data = synth.generate_host("geometric", n, seed=n % 1000)
+    rare = np.flatnonzero(lens >= 10)
+    assert rare.size
+    hits = rng.random(n) < 0.02
+    data[hits] = rng.choice(rare, size=int(hits.sum())).astype(np.uint8)
+    if n > 6 * 16384:  # one segment of long codes only: too dense for the image
+        data[4 * 16384:5 * 16384] = rng.choice(rare, size=16384).astype(np.uint8)
+    model = dev.DeviceModel(codes, lens)
+    ctx = model.ctx
+    enc = dev.encode(to_gpu(data), model)
+    try:
+        got = dev.decode(enc, model).cpu().numpy()
+        assert ctx.decode_kernel() == "dec_kernel_pair2"
+        ctx.set_option("debug", 1024)
+        one = dev.decode(enc, model).cpu().numpy()
+        assert ctx.decode_kernel() == "dec_kernel_reg (pairs)"
+    finally:
+        ctx.set_option("debug", 0)
+    assert np.array_equal(got, data)
+    assert np.array_equal(one, data)
+    assert np.array_equal(got, orc.decode_read(enc.stream().cpu().numpy(), codes, lens, n))

@@ -18,7 +18,7 @@ calls = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         m = re.search(r"(enc_pack_kernel<[^>]*>|enc_pack_stream_kernel<[^>]*>|enc_fix_tiles_kernel|enc_bytes_kernel|enc_tile_bits_kernel|enc_scan_tiles_kernel|"
-                      r"enc_plan_bits_kernel|dec_kernel_quad|gap_\w+_kernel(?:<[^>]*>)?|dec_kernel_reg<[^>]*>|dec_kernel<[^>]*>|hist_kernel<[^>]*>|"
+                      r"enc_plan_bits_kernel|dec_kernel_pair2<[^>]*>|gap_\w+_kernel(?:<[^>]*>)?|dec_kernel_reg<[^>]*>|dec_kernel<[^>]*>|hist_kernel<[^>]*>|"
                       r"hist_batches_kernel<[^>]*>)", r["Kernel_Name"])
         if not m:
             continue
