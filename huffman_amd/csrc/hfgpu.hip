@@ -1420,7 +1420,7 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
         void (*decode)(GapParams);
     };
 #define HF_GAP_KERNELS(W, E) GapKernels{gap_sync_kernel<W, E>, gap_emit_kernel<W, E>, gap_decode_kernel<W, E>}
-    const GapKernels kern =
+    GapKernels kern =
         per_window >= 8 ? (esc ? HF_GAP_KERNELS(8, true) : HF_GAP_KERNELS(8, false))
         : per_window >= 6 ? (esc ? HF_GAP_KERNELS(6, true) : HF_GAP_KERNELS(6, false))
         : per_window >= 5 ? (esc ? HF_GAP_KERNELS(5, true) : HF_GAP_KERNELS(5, false))
@@ -1429,6 +1429,10 @@ int gap_build(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint64_t 
         : per_window >= 2 ? HF_GAP_KERNELS(2, true)
                           : HF_GAP_KERNELS(1, true);
 #undef HF_GAP_KERNELS
+    // steep codes (a lane's 512 bits hold a dozen steps of sixteen codes and more): the
+    // last walk stores eight steps at a time
+    if (per_window >= 8 && model->mean_bits <= 3.0)
+        kern.decode = esc ? gap_decode_kernel<8, true, 8> : gap_decode_kernel<8, false, 8>;
     g.total_bits = in_bytes * 8;
     g.n_sub = (g.total_bits + GAP_SUB_BITS - 1) / GAP_SUB_BITS;
     g.n_wg = (g.n_sub + GAP_OWN - 1) / GAP_OWN;

@@ -427,9 +427,13 @@ __device__ __forceinline__ GapLane gap_last_walk_setup(const GapParams &g, uint8
 // places, which costs a store instruction sixteen times its aligned price, but
 // there is one per sixteen symbols.  A step that would reach the end of the
 // sub-sequence or of the output is done one code at a time.
-template <int W, bool ESC>
+// GAP_HOLD = steps whose stores leave together (see below): 1, or 8 for steep codes,
+// whose lanes take a dozen steps and more.
+template <int W, bool ESC, int GAP_HOLD = 1>
 __global__ __launch_bounds__(GAP_THREADS) void gap_decode_kernel(GapParams g)
 {
+    if (W == 6 && !ESC && GAP_HOLD == 1) // (this instantiation allocates exactly 32 VGPRs, see dev_common.hpp)
+        HF_TOUCH_VGPR("v32");
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t lut_bytes = (g.d.lut_entries * 2u + 15u) & ~15u;
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
@@ -445,39 +449,64 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_decode_kernel(GapParams g)
     const uint32_t end = L.end;
     bool bad = false;
     while (pos < end && s < n_out) {
+        // Up to GAP_HOLD steps of sixteen codes each are taken before anything is stored,
+        // and their 16-byte stores then leave back to back: with eight, 128 contiguous
+        // bytes reach the L2 together and are written to memory once.  (A store per step,
+        // a microsecond apart, with every lane of the chip writing somewhere else in
+        // between, has most lines written back several times, partly filled: 3.4 bytes
+        // written per symbol of the 4 GiB geometric stream, whose last walk that bounds.
+        // Streams of longer codes have five or six steps per lane; for them the grouping
+        // costs more than it saves, and they keep one step per round.)  A lane's steps
+        // stand from the first on, so `held` counts them.
+        uint4 hold[GAP_HOLD];
+        uint32_t held = 0;
+        bool failed = false;
         uint32_t pack[4] = {0, 0, 0, 0};
-        uint32_t used = 0, start_last = 0, wstart = 0;
-        uint64_t win = 0;
-        bool bad16 = false; // (only counts when the step stands: it may read past the bounds)
-        bool over = false;  // some window gave more than its 64 bits
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k % W == 0) {
+        for (int q = 0; q < GAP_HOLD; ++q) {
+            if (!failed && pos < end && s + 16u * held < n_out) {
+                uint32_t used = 0, start_last = 0, wstart = 0;
+                uint64_t win = 0;
+                bool bad16 = false; // (only counts when the step stands: it may read past the bounds)
+                bool over = false;  // some window gave more than its 64 bits
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k % W == 0) {
+                        over = over || used - wstart > 64u;
+                        wstart = used;
+                        win = gap_window(row, pos + used);
+                    }
+                    const uint32_t e = gap_entry<ESC>(win, s_lut, g.d, bad16);
+                    win <<= (e & 63u);
+                    start_last = used;
+                    used += HF_LUT_LEN(e);
+                    // byte k % 4 of the word takes byte 1 of the entry
+                    constexpr uint32_t keep = 0x03020100u;
+                    const uint32_t sel = (keep & ~(0xffu << (8 * (k & 3)))) | (0x05u << (8 * (k & 3)));
+                    pack[k >> 2] = __builtin_amdgcn_perm(e, pack[k >> 2], sel);
+                }
                 over = over || used - wstart > 64u;
-                wstart = used;
-                win = gap_window(row, pos + used);
+                if (pos + start_last < end && s + 16u * held + 16u <= n_out && !over) {
+                    hold[q] = make_uint4(pack[0], pack[1], pack[2], pack[3]);
+                    pos += used;
+                    ++held;
+                    bad = bad || bad16;
+                } else {
+                    failed = true;
+                }
             }
-            const uint32_t e = gap_entry<ESC>(win, s_lut, g.d, bad16);
-            win <<= (e & 63u);
-            start_last = used;
-            used += HF_LUT_LEN(e);
-            // byte k % 4 of the word takes byte 1 of the entry
-            constexpr uint32_t keep = 0x03020100u;
-            const uint32_t sel = (keep & ~(0xffu << (8 * (k & 3)))) | (0x05u << (8 * (k & 3)));
-            pack[k >> 2] = __builtin_amdgcn_perm(e, pack[k >> 2], sel);
         }
-        over = over || used - wstart > 64u;
-        if (pos + start_last < end && s + 16 <= n_out && !over) {
-            const uint4 v = make_uint4(pack[0], pack[1], pack[2], pack[3]);
-            __builtin_memcpy(out + s, &v, 16);
-            pos += used;
-            s += 16;
-            bad = bad || bad16;
-        } else {
+#pragma unroll
+        for (int q = 0; q < GAP_HOLD; ++q)
+            if ((uint32_t)q < held)
+                __builtin_memcpy(out + s + 16u * q, &hold[q], 16);
+        s += 16u * held;
+        if (failed) {
             // the same sixteen codes, each behind a look at the bounds (every lane comes
             // here once, at its end -- but its wave with it, in several of its steps)
             uint32_t nv = 0;    // codes that stand
             uint32_t since = 0; // codes taken from the current window (the same in all lanes)
+            uint64_t win = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 if (since == 0)
