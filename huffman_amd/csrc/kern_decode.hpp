@@ -730,13 +730,17 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_kernel_reg(DecParams p)
                         continue;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const uint32_t a = U[4 * u + d], c = U[4 * (u + step) + d];
-                        const uint32_t give = odd ? a : c;
-                        const uint32_t recv = (uint32_t)(stage == 0
-                            ? __builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xf, 0xf, false)   // quad_perm [1,0,3,2]
-                            : __builtin_amdgcn_update_dpp(0, (int)give, 0x4E, 0xf, 0xf, false)); // quad_perm [2,3,0,1]
-                        U[4 * u + d] = odd ? recv : a;
-                        U[4 * (u + step) + d] = odd ? c : recv;
+                        // even lane: keeps a, takes the partner's a; odd lane: takes the
+                        // partner's b, keeps b (one permute and one select per result)
+                        const uint32_t a = U[4 * u + d], b = U[4 * (u + step) + d];
+                        const uint32_t pa = (uint32_t)(stage == 0
+                            ? __builtin_amdgcn_update_dpp((int)a, (int)a, 0xB1, 0xf, 0xf, true)   // quad_perm [1,0,3,2]
+                            : __builtin_amdgcn_update_dpp((int)a, (int)a, 0x4E, 0xf, 0xf, true)); // quad_perm [2,3,0,1]
+                        const uint32_t pb = (uint32_t)(stage == 0
+                            ? __builtin_amdgcn_update_dpp((int)b, (int)b, 0xB1, 0xf, 0xf, true)
+                            : __builtin_amdgcn_update_dpp((int)b, (int)b, 0x4E, 0xf, 0xf, true));
+                        U[4 * u + d] = odd ? pb : a;
+                        U[4 * (u + step) + d] = odd ? b : pa;
                     }
                 }
             }
@@ -793,13 +797,17 @@ __device__ __forceinline__ void dec_store_chunk64(uint32_t (&U)[16], uint64_t c,
                 continue;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
+                // even lane: keeps a, takes the partner's a; odd lane: takes the partner's b,
+                // keeps b -- a select each, whose one operand comes through the quad permute
                 const uint32_t a = U[4 * u + d], b = U[4 * (u + step) + d];
-                const uint32_t give = odd ? a : b;
-                const uint32_t recv = (uint32_t)(stage == 0
-                    ? __builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xf, 0xf, false)
-                    : __builtin_amdgcn_update_dpp(0, (int)give, 0x4E, 0xf, 0xf, false));
-                U[4 * u + d] = odd ? recv : a;
-                U[4 * (u + step) + d] = odd ? b : recv;
+                const uint32_t pa = (uint32_t)(stage == 0
+                    ? __builtin_amdgcn_update_dpp((int)a, (int)a, 0xB1, 0xf, 0xf, true)
+                    : __builtin_amdgcn_update_dpp((int)a, (int)a, 0x4E, 0xf, 0xf, true));
+                const uint32_t pb = (uint32_t)(stage == 0
+                    ? __builtin_amdgcn_update_dpp((int)b, (int)b, 0xB1, 0xf, 0xf, true)
+                    : __builtin_amdgcn_update_dpp((int)b, (int)b, 0x4E, 0xf, 0xf, true));
+                U[4 * u + d] = odd ? pb : a;
+                U[4 * (u + step) + d] = odd ? b : pa;
             }
         }
     }
