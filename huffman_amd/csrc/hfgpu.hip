@@ -868,7 +868,8 @@ int encode_launch(hf_ctx *ctx, const hf_model *model, const uint8_t *d_in, uint6
         const uint64_t spans = (n >> 4) / ((uint64_t)ENCB_VECS * ENCB_THREADS);
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spans, (uint64_t)ctx->num_cus * 2));
         const uint32_t cs = d_chunk_bits ? chunk_syms : 64;
-        auto kern = enc_bytes_kernel;
+        // (non-temporal accesses from 256 MiB on, like the counting pass)
+        auto kern = n >= (256ull << 20) ? enc_bytes_kernel<true> : enc_bytes_kernel<false>;
         ctx->encode_kernel = "enc_bytes_kernel";
         if (!fixed_scratch)
             HF_TIMED_LAUNCH(ctx, HF_TIMED_ENCODE,

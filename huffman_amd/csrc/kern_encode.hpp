@@ -1486,6 +1486,31 @@ __device__ __forceinline__ uint32_t encb_map4(const uint8_t *s_code, uint32_t v)
     return a | (b << 8) | (c << 16) | (d << 24);
 }
 
+// STREAM: loads and stores both non-temporal, for inputs far larger than the caches
+// (a plain copy kernel gains 10 % that way, this kernel 3 %: 1 GiB 0.424 -> 0.411 ms;
+// either alone is slower than plain accesses).
+typedef uint32_t encb_u32x4 __attribute__((ext_vector_type(4)));
+template <bool STREAM>
+__device__ __forceinline__ uint4 encb_load(const uint4 *p)
+{
+    if (STREAM) {
+        const encb_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const encb_u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+template <bool STREAM>
+__device__ __forceinline__ void encb_store(uint4 *p, uint4 y)
+{
+    if (STREAM) {
+        encb_u32x4 w;
+        w.x = y.x, w.y = y.y, w.z = y.z, w.w = y.w;
+        __builtin_nontemporal_store(w, reinterpret_cast<encb_u32x4 *>(p));
+    } else {
+        *p = y;
+    }
+}
+template <bool STREAM>
 __global__ __launch_bounds__(ENCB_THREADS) void enc_bytes_kernel(
     const uint8_t *__restrict__ in, uint64_t n, const uint64_t *__restrict__ tab,
     uint8_t *__restrict__ out, uint64_t out_cap, uint32_t chunk_syms,
@@ -1524,7 +1549,7 @@ __global__ __launch_bounds__(ENCB_THREADS) void enc_bytes_kernel(
         const uint4 *src = vin + sp * SPAN + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < ENCB_VECS; ++k) {
-            x[k] = src[k * ENCB_THREADS];
+            x[k] = encb_load<STREAM>(src + k * ENCB_THREADS);
             __builtin_amdgcn_sched_barrier(0); // in the order in which the loop refills them
         }
 #pragma nounroll
@@ -1539,9 +1564,9 @@ __global__ __launch_bounds__(ENCB_THREADS) void enc_bytes_kernel(
                 uint4 y;
                 y.x = encb_map4(s_code, x[k].x), y.y = encb_map4(s_code, x[k].y);
                 y.z = encb_map4(s_code, x[k].z), y.w = encb_map4(s_code, x[k].w);
-                dst[k * ENCB_THREADS] = y;
+                encb_store<STREAM>(dst + k * ENCB_THREADS, y);
                 __builtin_amdgcn_sched_barrier(0); // the refill goes into the registers just mapped
-                x[k] = src[k * step];
+                x[k] = encb_load<STREAM>(src + k * step);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
