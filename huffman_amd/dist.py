@@ -136,8 +136,10 @@ def plan_from_histograms(hists, lens, rank: int) -> ShardPlan:
     if int(ln.max(initial=0)) > 64:
         raise ValueError("code length above 64")
     world = h.shape[0]
-    # (Python integers: a shard of 2^58 symbols times 64 bits does not fit 64 bits)
-    bits = [sum(int(c) * int(l) for c, l in zip(h[r], ln) if c) for r in range(world)]
+    if float(h.sum(dtype=np.float64)) * 64.0 < 2.0 ** 62:
+        bits = [int(b) for b in (h * ln[None, :]).sum(axis=1, dtype=np.uint64)]
+    else:  # (Python integers: shards of 2^58 symbols times 64 bits do not fit 64 bits)
+        bits = [sum(int(c) * int(l) for c, l in zip(h[r], ln) if c) for r in range(world)]
     start, acc = [], 0
     for b in bits:
         start.append(acc)
