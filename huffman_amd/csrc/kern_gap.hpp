@@ -138,20 +138,32 @@ __device__ __forceinline__ uint32_t gap_walk(const uint32_t *row, uint32_t start
                                              uint32_t &count, bool &bad)
 {
     uint32_t pos = start, c = 0;
+    // Windows of W codes, unchecked, for as long as they stand; a window that does not
+    // (the lane's last one as a rule, rarely codes that exceed the 64 bits) is done again
+    // code by code -- behind the inner loop, where the lanes of a wave meet again: inside
+    // it, every lane that reaches its end would take the whole wave through that path.
     while (pos < end) {
-        uint64_t win = gap_window(row, pos);
-        uint32_t esum = 0, before_last = 0; // low byte: bits taken (at most 64)
+        bool ok = true;
+        uint64_t win = 0;
+        while (ok && pos < end) {
+            win = gap_window(row, pos);
+            uint32_t esum = 0, before_last = 0; // low byte: bits taken (at most 64)
+            bool bad_w = false; // (only counts when the window stands: it may look past the bounds)
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-            const uint32_t e = gap_entry<ESC>(win, s_lut, p, bad);
-            win <<= (e & 63u);
-            before_last = esum;
-            esum += e;
+            for (int k = 0; k < W; ++k) {
+                const uint32_t e = gap_entry<ESC>(win, s_lut, p, bad_w);
+                win <<= (e & 63u);
+                before_last = esum;
+                esum += e;
+            }
+            ok = pos + (before_last & 0xffu) < end && (esum & 0xffu) <= 64u;
+            if (ok) {
+                pos += esum & 0xffu;
+                c += W;
+                bad = bad || bad_w;
+            }
         }
-        if (pos + (before_last & 0xffu) < end && (esum & 0xffu) <= 64u) {
-            pos += esum & 0xffu;
-            c += W;
-        } else {
+        if (!ok) {
             uint32_t since = 0; // codes taken from the current window (the same in all lanes)
 #pragma unroll
             for (int k = 0; k < W; ++k) {
@@ -458,10 +470,14 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_decode_kernel(GapParams g)
         // Streams of longer codes have five or six steps per lane; for them the grouping
         // costs more than it saves, and they keep one step per round.)  A lane's steps
         // stand from the first on, so `held` counts them.
-        uint4 hold[GAP_HOLD];
-        uint32_t held = 0;
+        // The rounds go on for as long as their steps stand; the step that does not (a
+        // lane's last, as a rule) is done again code by code behind the inner loop, where
+        // the lanes of a wave meet again.
         bool failed = false;
         uint32_t pack[4] = {0, 0, 0, 0};
+        while (!failed && pos < end && s < n_out) {
+        uint4 hold[GAP_HOLD];
+        uint32_t held = 0;
 #pragma unroll
         for (int q = 0; q < GAP_HOLD; ++q) {
             if (!failed && pos < end && s + 16u * held < n_out) {
@@ -501,6 +517,7 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_decode_kernel(GapParams g)
             if ((uint32_t)q < held)
                 __builtin_memcpy(out + s + 16u * q, &hold[q], 16);
         s += 16u * held;
+        }
         if (failed) {
             // the same sixteen codes, each behind a look at the bounds (every lane comes
             // here once, at its end -- but its wave with it, in several of its steps)
@@ -587,31 +604,38 @@ __global__ __launch_bounds__(GAP_THREADS) void gap_emit_kernel(GapParams g)
             g.seg_off[c / HF_SEG_CHUNKS] = g.bit_base + L.bit0 + at;
     };
     while (pos < end && s < n_out) {
-        uint32_t st[4], used = 0, wstart = 0;
+        // unchecked steps for as long as they stand; the one that does not is done again
+        // code by code behind the inner loop, where the lanes of a wave meet again
+        bool ok = true;
         uint64_t win = 0;
-        bool bad4 = false; // (only counts when the step stands: it may read past the bounds)
-        bool over = false; // some window gave more than its 64 bits
+        while (ok && pos < end && s < n_out) {
+            uint32_t st[4], used = 0, wstart = 0;
+            bool bad4 = false; // (only counts when the step stands: it may read past the bounds)
+            bool over = false; // some window gave more than its 64 bits
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k % W == 0) {
-                over = over || used - wstart > 64u;
-                wstart = used;
-                win = gap_window(row, pos + used);
+            for (int k = 0; k < 4; ++k) {
+                if (k % W == 0) {
+                    over = over || used - wstart > 64u;
+                    wstart = used;
+                    win = gap_window(row, pos + used);
+                }
+                const uint32_t e = gap_entry<ESC>(win, s_lut, g.d, bad4);
+                win <<= (e & 63u);
+                st[k] = used;
+                used += HF_LUT_LEN(e);
             }
-            const uint32_t e = gap_entry<ESC>(win, s_lut, g.d, bad4);
-            win <<= (e & 63u);
-            st[k] = used;
-            used += HF_LUT_LEN(e);
+            over = over || used - wstart > 64u;
+            ok = pos + st[3] < end && s + 4 <= n_out && !over;
+            if (ok) {
+                const uint32_t k_open = (cs - ((uint32_t)s & (cs - 1u))) & (cs - 1u); // 0..3: s + k_open opens a chunk
+                if (k_open < 4u)
+                    open_chunk(s + k_open, pos + (k_open == 0 ? st[0] : k_open == 1 ? st[1] : k_open == 2 ? st[2] : st[3]));
+                pos += used;
+                s += 4;
+                bad = bad || bad4;
+            }
         }
-        over = over || used - wstart > 64u;
-        if (pos + st[3] < end && s + 4 <= n_out && !over) {
-            const uint32_t k_open = (cs - ((uint32_t)s & (cs - 1u))) & (cs - 1u); // 0..3: s + k_open opens a chunk
-            if (k_open < 4u)
-                open_chunk(s + k_open, pos + (k_open == 0 ? st[0] : k_open == 1 ? st[1] : k_open == 2 ? st[2] : st[3]));
-            pos += used;
-            s += 4;
-            bad = bad || bad4;
-        } else {
+        if (!ok) {
             uint32_t since = 0; // codes taken from the current window (the same in all lanes)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
